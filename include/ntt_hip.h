@@ -1,0 +1,137 @@
+/*
+ * ntt_hip.h -- C-ABI of libntt_hip.so, the MI355X (gfx950) NTT engine.
+ *
+ * This is the drop-in boundary for the hot path of hal-lab-u-tokyo/ntt-aie.
+ * Citations are file:line under the reference tree.  The reference launches its
+ * device graph as
+ *     kernel(bo_instr, n_instr, bo_inA, bo_root, bo_outC); run.wait();
+ *                                                   (src/test.cpp:159-160, 181-182)
+ * whose runtime sequence is sequence(input, root, output) over three
+ * memref<N x i32> (src/aie2.py:320-337).  The same three buffers -- input
+ * coefficients, twiddle table "root", output -- are what this library takes;
+ * (bo_instr, n_instr) are the AIE instruction stream and have no counterpart.
+ *
+ * Conventions
+ *   - plain C: opaque handle, raw device/host pointers, sizes; no C++/torch types.
+ *   - every entry point returns int: 0 = ok, negative = NTT_E_* argument/state
+ *     error, positive = hipError_t from the runtime.  Nothing throws or aborts
+ *     (reference error contract: ERT state != COMPLETED -> message + return 1,
+ *     src/test.cpp:162-166).
+ *   - device buffers are caller-owned; polynomials are contiguous [batch][N]
+ *     words in the reference's element order (natural order in, src/test.cpp:141).
+ *     Words are uint32_t (any odd p < 2^32) or uint64_t (p = 2^64 - 2^32 + 1).
+ *     Coefficients and twiddles must be canonical residues in [0, p) (the
+ *     precondition of vector_modadd / vector_modsub, src/aie_core.cc:41-62).
+ *   - launches are asynchronous on the caller's hipStream_t (passed as void*;
+ *     NULL = default stream).  A plan is immutable after ntt_plan_set_twiddles
+ *     and may be shared by host threads; one plan per device.
+ *   - no hidden allocation per call: the plan owns its device twiddle copies.
+ */
+#ifndef NTT_HIP_H
+#define NTT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ntt_plan *ntt_plan_t;
+
+/* error codes (negative) */
+enum {
+    NTT_OK = 0,
+    NTT_E_ARG = -1,        /* null pointer / size out of range */
+    NTT_E_PRIME = -2,      /* p even, p >= 2^32 for 4-byte words, or not Goldilocks for 8-byte words */
+    NTT_E_LOGN = -3,       /* logn outside [1, NTT_MAX_LOGN] */
+    NTT_E_NOTABLE = -4,    /* transform requested before ntt_plan_set_twiddles */
+    NTT_E_NOTINVERTIBLE = -5, /* inverse requested but a needed twiddle is 0 mod p */
+    NTT_E_LAYOUT = -6,     /* NTT_LAYOUT_AIE_BLOCK16 needs N >= 16 */
+    NTT_E_RANGE = -7,      /* a twiddle handed to set_twiddles is >= p */
+    NTT_E_NODEVICE = -8    /* no HIP device / device index out of range */
+};
+
+#define NTT_MAX_LOGN 28
+
+/* element order of the transform-domain buffer */
+enum {
+    NTT_LAYOUT_NATURAL = 0,
+    /* the reference device's output order: 16 blocks of N/16 words, block
+     * ans_order[i] holds natural block i (src/test.cpp:69-71, 212-219; caused by the
+     * two tile swaps src/aie2.py:192-209, 257-265) */
+    NTT_LAYOUT_AIE_BLOCK16 = 1
+};
+
+/* library / build identification: returns 10000*major + 100*minor + patch */
+int ntt_version(void);
+const char *ntt_error_string(int code);
+/* number of visible HIP devices (0 if none); never fails */
+int ntt_device_count(void);
+
+/* ---- plan -----------------------------------------------------------------
+ * Replaces the compile-time constants the reference bakes into every tile call
+ * (logN, p, Barrett w/u: src/aie2.py:14-19, 178-306; src/test.cpp:66, 76-77).
+ * word_bytes = 4 -> uint32_t words, odd p < 2^32 (Montgomery arithmetic on the
+ * device: results are canonical, hence equal to the reference's Barrett words,
+ * src/aie_core.cc:27-39, 64-102); word_bytes = 8 -> p must be 2^64-2^32+1. */
+int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int device);
+int ntt_plan_destroy(ntt_plan_t plan);
+
+/* The "root" buffer (bo_root, src/test.cpp:119-120, 137-143, 150): N words,
+ * T[0] unused, T[h+i] is the twiddle of block i at the stage with h blocks
+ * (src/test.cpp:45).  Copied to the device (and pre-transformed for the
+ * arithmetic the kernels use); the inverse table T^-1 is derived here.
+ * host_T is a HOST pointer; synchronous. */
+int ntt_plan_set_twiddles(ntt_plan_t plan, const void *host_T);
+
+/* Table rule of the reference host (make_roots + modPow + root[0] = 1,
+ * src/test.cpp:15-32, 138): w = g^((p-1)/N) with integer division,
+ * T[i] = T[i-1]*w mod p.  Fills host_T (N words of the plan's word size). */
+int ntt_make_roots(ntt_plan_t plan, uint64_t g, void *host_T);
+/* Tables that make the same network a genuine transform:
+ *   kind 1: cyclic  T[h+i] = w^(bitrev(i) * N/(2h)),  w = g^((p-1)/N)
+ *   kind 2: negacyclic (Longa-Naehrig) T[k] = psi^-bitrev(k), psi = g^((p-1)/(2N))
+ * (kind 0 = ntt_make_roots).  Returns NTT_E_ARG when N does not divide the order. */
+int ntt_make_table(ntt_plan_t plan, int kind, uint64_t g, void *host_T);
+
+/* plan introspection (for harnesses): 0 logn, 1 word_bytes, 2 device,
+ * 3 number of HBM passes of one forward transform, 4 has-inverse-table */
+int64_t ntt_plan_info(ntt_plan_t plan, int what);
+
+/* ---- transforms ------------------------------------------------------------
+ * Forward = the reference network (src/test.cpp:34-60; tile kernels
+ * src/aie_core.cc:161-187, 189-361): stage s = 0..logN-1, stride 2^s,
+ *   (x, y) -> (x + y, (x - y) * T[N/2^(s+1) + block])  mod p.
+ * d_in natural order, d_out in `out_layout`; d_in == d_out allowed (in place).
+ * batch polynomials, contiguous. */
+int ntt_forward(ntt_plan_t plan, const void *d_in, void *d_out, size_t batch,
+                int out_layout, void *stream);
+
+/* Exact inverse of ntt_forward (no reference counterpart; BASELINE configs 3-4):
+ * stages logN-1..0, (u, v) -> (u + v/T, u - v/T), then * N^-1 when scale != 0.
+ * d_in is in `in_layout` (what ntt_forward produced), d_out natural order. */
+int ntt_inverse(ntt_plan_t plan, const void *d_in, void *d_out, size_t batch,
+                int in_layout, int scale, void *stream);
+
+/* d_out[i] = d_a[i] * d_b[i] * scale mod p over batch*N words (scale in [0,p),
+ * 1 = plain product).  Any of the pointers may alias. */
+int ntt_pointwise_mul(ntt_plan_t plan, const void *d_a, const void *d_b, void *d_out,
+                      size_t batch, uint64_t scale, void *stream);
+
+/* Negacyclic product c = a*b mod (x^N + 1, p) with a kind-2 table loaded:
+ * inverse-network (unscaled) on a and b -> pointwise * N^-1... folded constant
+ * -> forward network.  d_a and d_b are overwritten (used as scratch);
+ * d_out may alias d_a. */
+int ntt_polymul_negacyclic(ntt_plan_t plan, void *d_a, void *d_b, void *d_out,
+                           size_t batch, void *stream);
+
+/* Reference-style partial network (test_stage hook, src/test.cpp:55-58, 67):
+ * run stages 0..stage only.  Slow path (one launch per stage), for bring-up. */
+int ntt_forward_stages(ntt_plan_t plan, const void *d_in, void *d_out, size_t batch,
+                       int stage, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,77 @@
+"""ctypes binding of libntt_hip.so (include/ntt_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to
+load, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libntt_hip.so")
+
+# error codes of include/ntt_hip.h
+NTT_OK = 0
+NTT_E_ARG = -1
+NTT_E_PRIME = -2
+NTT_E_LOGN = -3
+NTT_E_NOTABLE = -4
+NTT_E_NOTINVERTIBLE = -5
+NTT_E_LAYOUT = -6
+NTT_E_RANGE = -7
+NTT_E_NODEVICE = -8
+
+LAYOUT_NATURAL = 0
+LAYOUT_AIE_BLOCK16 = 1
+
+# every symbol include/ntt_hip.h declares
+EXPORTS = (
+    "ntt_version", "ntt_error_string", "ntt_device_count", "ntt_plan_create", "ntt_plan_destroy",
+    "ntt_plan_set_twiddles", "ntt_make_roots", "ntt_make_table", "ntt_plan_info", "ntt_forward",
+    "ntt_inverse", "ntt_pointwise_mul", "ntt_polymul_negacyclic", "ntt_forward_stages",
+)
+
+
+class NTTError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        self.code = code
+        msg = lib().ntt_error_string(code)
+        super().__init__("%s failed: %d (%s)" % (where, code, msg.decode() if msg else "?"))
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libntt_hip.so is not built (%s). Build it with `make -C ntt_aie_amd/csrc` or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+        L.ntt_version.restype = C.c_int
+        L.ntt_error_string.restype = C.c_char_p
+        L.ntt_error_string.argtypes = [C.c_int]
+        L.ntt_device_count.restype = C.c_int
+        L.ntt_plan_create.argtypes = [C.POINTER(vp), C.c_int, u64, C.c_int, C.c_int]
+        L.ntt_plan_destroy.argtypes = [vp]
+        L.ntt_plan_set_twiddles.argtypes = [vp, vp]
+        L.ntt_make_roots.argtypes = [vp, u64, vp]
+        L.ntt_make_table.argtypes = [vp, C.c_int, u64, vp]
+        L.ntt_plan_info.restype = C.c_int64
+        L.ntt_plan_info.argtypes = [vp, C.c_int]
+        L.ntt_forward.argtypes = [vp, vp, vp, sz, C.c_int, vp]
+        L.ntt_inverse.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, vp]
+        L.ntt_pointwise_mul.argtypes = [vp, vp, vp, vp, sz, u64, vp]
+        L.ntt_polymul_negacyclic.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.ntt_forward_stages.argtypes = [vp, vp, vp, sz, C.c_int, vp]
+        _lib = L
+    return _lib
+
+
+def check(code: int, where: str) -> None:
+    if code != 0:
+        raise NTTError(code, where)

@@ -1,0 +1,46 @@
+// kernels.h -- type-erased launch interface between the C-ABI (ntt_api.hip) and
+// the per-field / per-direction kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pass.h"
+
+namespace ntt {
+
+// Column tile width: 2^LOG_COLS consecutive words per row segment (128 B for
+// 8-byte words, 64 B for 4-byte words).
+constexpr int LOG_COLS = 4;
+
+struct ErasedArgs {
+    const void *in;
+    void *out;
+    const void *tw;
+    uint32_t p, pinv, r2;  // FieldM32 parameters (ignored by FieldGL)
+    int n, s0;
+    uint32_t batch;
+    int layout;
+    int do_scale;
+    uint64_t scale;  // table form
+    uint32_t target_wgs;
+};
+
+// Each returns hipSuccess / a hipError_t; hipErrorInvalidValue for an
+// unsupported (contig, log_m) combination.
+hipError_t launch_gl_fwd(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
+hipError_t launch_gl_inv(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
+hipError_t launch_m32_fwd(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
+hipError_t launch_m32_inv(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
+
+// elementwise c = a*b*scale (scale in plain form; scale == 1 skips the second product)
+hipError_t launch_pointwise_gl(const void *a, const void *b, void *c, size_t count, uint64_t scale,
+                               hipStream_t s);
+hipError_t launch_pointwise_m32(const void *a, const void *b, void *c, size_t count, uint32_t p,
+                                uint32_t pinv, uint32_t r2, uint32_t scale, hipStream_t s);
+
+// one stage of the network, one thread per butterfly (bring-up path, test_stage hook)
+hipError_t launch_stage_gl(void *data, const void *tw, int n, int stage, size_t batch, hipStream_t s);
+hipError_t launch_stage_m32(void *data, const void *tw, int n, int stage, size_t batch, uint32_t p,
+                            uint32_t pinv, uint32_t r2, hipStream_t s);
+
+}  // namespace ntt

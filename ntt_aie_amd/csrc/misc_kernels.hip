@@ -1,0 +1,113 @@
+// misc_kernels.hip -- the small kernels around the pass kernels:
+//   * pointwise product (config 4's middle leg; no reference counterpart),
+//   * one-stage-per-launch network (the reference's test_stage hook,
+//     src/test.cpp:55-58, 67: "run stages 0..stage and stop"), one thread per
+//     butterfly exactly as src/test.cpp:42-51 enumerates them.  Bring-up path
+//     and an independent second GPU implementation for the parity tests.
+#include <hip/hip_runtime.h>
+
+#include "field.h"
+#include "kernels.h"
+
+namespace ntt {
+namespace {
+
+template <class W, int V>
+struct alignas(sizeof(W) * V) Vec {
+    W v[V];
+};
+
+template <class F>
+__global__ __launch_bounds__(256) void pointwise_kernel(const typename F::W *a, const typename F::W *b,
+                                                        typename F::W *c, size_t count, F f,
+                                                        typename F::W scale, int use_scale) {
+    using W = typename F::W;
+    constexpr int V = 16 / sizeof(W);
+    using Ch = Vec<W, V>;
+    const size_t nchunks = count / V;  // count is a multiple of N >= 2; tail handled below
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+        Ch x = reinterpret_cast<const Ch *>(a)[i];
+        Ch y = reinterpret_cast<const Ch *>(b)[i];
+        Ch z;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            W t = f.mul_plain(x.v[k], y.v[k]);
+            z.v[k] = use_scale ? f.mul_plain(t, scale) : t;
+        }
+        reinterpret_cast<Ch *>(c)[i] = z;
+    }
+    // tail (count not a multiple of V: only N = 2 with 4-byte words and odd batch)
+    for (size_t i = nchunks * V + (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        W t = f.mul_plain(a[i], b[i]);
+        c[i] = use_scale ? f.mul_plain(t, scale) : t;
+    }
+}
+
+// stage s: t = 2^s, butterfly k of a polynomial: block i = k >> s, j = (i << (s+1)) | (k & (t-1))
+template <class F>
+__global__ __launch_bounds__(256) void stage_kernel(typename F::W *data, const typename F::W *tw, int n,
+                                                    int s, size_t total_bf, F f) {
+    using W = typename F::W;
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    const int half = n - 1;
+    for (size_t g = (size_t) blockIdx.x * blockDim.x + threadIdx.x; g < total_bf; g += stride) {
+        const size_t poly = g >> half;
+        const uint32_t k = (uint32_t) (g & ((1u << half) - 1u));
+        const uint32_t t = 1u << s;
+        const uint32_t i = k >> s;
+        const uint32_t j = (i << (s + 1)) | (k & (t - 1u));
+        const uint32_t h = 1u << (n - s - 1);
+        W *a = data + (poly << n);
+        const W root = tw[h + i];  // table form
+        const W v0 = a[j], v1 = a[j + t];
+        a[j] = f.add(v0, v1);
+        a[j + t] = f.mul(f.sub(v0, v1), root);
+    }
+}
+
+inline unsigned grid_for(size_t work) {
+    size_t g = (work + 255) / 256;
+    if (g > 8192) g = 8192;  // 256 CUs x 8 x 4: grid-stride the rest
+    if (g == 0) g = 1;
+    return (unsigned) g;
+}
+
+}  // namespace
+
+hipError_t launch_pointwise_gl(const void *a, const void *b, void *c, size_t count, uint64_t scale,
+                               hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(pointwise_kernel<FieldGL>, dim3(grid_for(count / 2)), dim3(256), 0, s,
+                       (const uint64_t *) a, (const uint64_t *) b, (uint64_t *) c, count, FieldGL{}, scale,
+                       scale != 1 ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_pointwise_m32(const void *a, const void *b, void *c, size_t count, uint32_t p,
+                                uint32_t pinv, uint32_t r2, uint32_t scale, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(pointwise_kernel<FieldM32>, dim3(grid_for(count / 4)), dim3(256), 0, s,
+                       (const uint32_t *) a, (const uint32_t *) b, (uint32_t *) c, count,
+                       FieldM32{p, pinv, r2}, scale, scale != 1 ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_gl(void *data, const void *tw, int n, int stage, size_t batch, hipStream_t s) {
+    const size_t total = batch << (n - 1);
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(stage_kernel<FieldGL>, dim3(grid_for(total)), dim3(256), 0, s, (uint64_t *) data,
+                       (const uint64_t *) tw, n, stage, total, FieldGL{});
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_m32(void *data, const void *tw, int n, int stage, size_t batch, uint32_t p,
+                            uint32_t pinv, uint32_t r2, hipStream_t s) {
+    const size_t total = batch << (n - 1);
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(stage_kernel<FieldM32>, dim3(grid_for(total)), dim3(256), 0, s, (uint32_t *) data,
+                       (const uint32_t *) tw, n, stage, total, FieldM32{p, pinv, r2});
+    return hipGetLastError();
+}
+
+}  // namespace ntt

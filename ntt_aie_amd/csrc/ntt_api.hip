@@ -1,0 +1,346 @@
+// ntt_api.hip -- C-ABI of libntt_hip.so (include/ntt_hip.h): plan, pass planner,
+// twiddle preparation and launch sequencing.  Host side of what the reference
+// does in src/test.cpp:62-190 (buffers, table, launch) minus XRT.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/ntt_hip.h"
+#include "kernels.h"
+#include "plan.h"
+
+using namespace ntt::host;
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void) hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+struct ntt_plan {
+    int logn;
+    uint64_t p;
+    int word_bytes;
+    int device;
+    // FieldM32 parameters
+    uint32_t pinv, r2;
+    // device tables, table form
+    void *d_tw_fwd;
+    void *d_tw_inv;
+    bool has_table, has_inv;
+    uint64_t scale_tf;     // N^-1 in table form
+    uint64_t ninv_plain;   // N^-1 plain
+    uint32_t target_wgs;
+    std::vector<PassDesc> passes;
+};
+
+namespace {
+
+size_t table_bytes(const ntt_plan *pl) { return ((size_t) 1 << pl->logn) * pl->word_bytes; }
+
+ntt::ErasedArgs base_args(const ntt_plan *pl, const PassDesc &pd, const void *in, void *out, size_t batch) {
+    ntt::ErasedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = in;
+    a.out = out;
+    a.p = (uint32_t) pl->p;
+    a.pinv = pl->pinv;
+    a.r2 = pl->r2;
+    a.n = pl->logn;
+    a.s0 = pd.s0;
+    a.batch = (uint32_t) batch;
+    a.target_wgs = pl->target_wgs;
+    return a;
+}
+
+int check_io(const ntt_plan *pl, const void *a, const void *b, size_t batch) {
+    if (!pl || !a || !b) return NTT_E_ARG;
+    if (((uintptr_t) a | (uintptr_t) b) & 15u) return NTT_E_ARG;  // 16-byte vector accesses
+    if (batch > 0x7FFFFFFFull) return NTT_E_ARG;
+    return NTT_OK;
+}
+
+int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int layout, hipStream_t s) {
+    const void *src = d_in;
+    for (const PassDesc &pd : pl->passes) {
+        ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
+        a.tw = pl->d_tw_fwd;
+        a.layout = layout;
+        hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_fwd(pd.contig, pd.log_m, a, s)
+                                           : ntt::launch_m32_fwd(pd.contig, pd.log_m, a, s);
+        if (e != hipSuccess) return (int) e;
+        src = d_out;
+    }
+    return NTT_OK;
+}
+
+int run_inverse(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int layout, int scale,
+                hipStream_t s) {
+    const void *src = d_in;
+    for (size_t i = pl->passes.size(); i-- > 0;) {
+        const PassDesc &pd = pl->passes[i];
+        ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
+        a.tw = pl->d_tw_inv;
+        a.layout = layout;
+        a.do_scale = (scale && i == 0) ? 1 : 0;
+        a.scale = pl->scale_tf;
+        hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_inv(pd.contig, pd.log_m, a, s)
+                                           : ntt::launch_m32_inv(pd.contig, pd.log_m, a, s);
+        if (e != hipSuccess) return (int) e;
+        src = d_out;
+    }
+    return NTT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ntt_version(void) { return 100; /* 0.1.0 */ }
+
+const char *ntt_error_string(int code) {
+    switch (code) {
+        case NTT_OK: return "ok";
+        case NTT_E_ARG: return "invalid argument (null / misaligned pointer, size out of range)";
+        case NTT_E_PRIME: return "unsupported modulus for this word size";
+        case NTT_E_LOGN: return "logn out of range";
+        case NTT_E_NOTABLE: return "twiddle table not set";
+        case NTT_E_NOTINVERTIBLE: return "twiddle table has an entry that is 0 mod p";
+        case NTT_E_LAYOUT: return "AIE_BLOCK16 layout needs N >= 16";
+        case NTT_E_RANGE: return "twiddle out of range [0, p)";
+        case NTT_E_NODEVICE: return "no such HIP device";
+        default: break;
+    }
+    if (code > 0) return hipGetErrorString((hipError_t) code);
+    return "unknown error";
+}
+
+int ntt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int device) {
+    if (!out) return NTT_E_ARG;
+    *out = nullptr;
+    if (word_bytes != 4 && word_bytes != 8) return NTT_E_ARG;
+    if (logn < 1 || logn > NTT_MAX_LOGN) return NTT_E_LOGN;
+    if (word_bytes == 8) {
+        if (p != GOLDILOCKS) return NTT_E_PRIME;
+    } else {
+        if ((p & 1) == 0 || p < 3 || p > 0xFFFFFFFFull) return NTT_E_PRIME;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return NTT_E_NODEVICE;
+    ntt_plan *pl = new (std::nothrow) ntt_plan();
+    if (!pl) return NTT_E_ARG;
+    pl->logn = logn;
+    pl->p = p;
+    pl->word_bytes = word_bytes;
+    pl->device = device;
+    pl->d_tw_fwd = pl->d_tw_inv = nullptr;
+    pl->has_table = pl->has_inv = false;
+    pl->pinv = pl->r2 = 0;
+    if (word_bytes == 4) {
+        pl->pinv = mont_pinv((uint32_t) p);
+        pl->r2 = mont_r2((uint32_t) p);
+    }
+    pl->ninv_plain = powmod((p + 1) / 2, (uint64_t) logn, p);  // (2^-1)^logn; p + 1 < 2^64
+    pl->scale_tf = to_table_form(pl->ninv_plain, p, word_bytes);
+    pl->target_wgs = 2048;
+    if (const char *e = getenv("NTT_TARGET_WGS")) {
+        long v = atol(e);
+        if (v > 0 && v < (1 << 24)) pl->target_wgs = (uint32_t) v;
+    }
+    pl->passes = plan_passes(logn);
+    DeviceGuard g(device);
+    if (g.err != hipSuccess) {
+        delete pl;
+        return (int) g.err;
+    }
+    hipError_t e = hipMalloc(&pl->d_tw_fwd, table_bytes(pl));
+    if (e == hipSuccess) e = hipMalloc(&pl->d_tw_inv, table_bytes(pl));
+    if (e != hipSuccess) {
+        if (pl->d_tw_fwd) (void) hipFree(pl->d_tw_fwd);
+        delete pl;
+        return (int) e;
+    }
+    *out = pl;
+    return NTT_OK;
+}
+
+int ntt_plan_destroy(ntt_plan_t pl) {
+    if (!pl) return NTT_E_ARG;
+    DeviceGuard g(pl->device);
+    if (pl->d_tw_fwd) (void) hipFree(pl->d_tw_fwd);
+    if (pl->d_tw_inv) (void) hipFree(pl->d_tw_inv);
+    delete pl;
+    return NTT_OK;
+}
+
+int ntt_plan_set_twiddles(ntt_plan_t pl, const void *host_T) {
+    if (!pl || !host_T) return NTT_E_ARG;
+    const size_t N = (size_t) 1 << pl->logn;
+    const uint64_t p = pl->p;
+    std::vector<uint64_t> T(N), Ti(N, 0);
+    for (size_t i = 0; i < N; i++)
+        T[i] = pl->word_bytes == 4 ? ((const uint32_t *) host_T)[i] : ((const uint64_t *) host_T)[i];
+    for (size_t i = 1; i < N; i++)
+        if (T[i] >= p) return NTT_E_RANGE;
+    T[0] %= p;  // T[0] is never read by the network (src/test.cpp:45 uses h+i >= 1)
+    const bool inv_ok = invert_table(T, p, Ti);
+    std::vector<unsigned char> buf_f(table_bytes(pl)), buf_i(table_bytes(pl));
+    if (pl->word_bytes == 4) {
+        for (size_t i = 0; i < N; i++) {
+            ((uint32_t *) buf_f.data())[i] = (uint32_t) to_table_form(T[i], p, 4);
+            ((uint32_t *) buf_i.data())[i] = (uint32_t) to_table_form(Ti[i], p, 4);
+        }
+    } else {
+        memcpy(buf_f.data(), T.data(), N * 8);
+        memcpy(buf_i.data(), Ti.data(), N * 8);
+    }
+    DeviceGuard g(pl->device);
+    if (g.err != hipSuccess) return (int) g.err;
+    hipError_t e = hipMemcpy(pl->d_tw_fwd, buf_f.data(), buf_f.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pl->d_tw_inv, buf_i.data(), buf_i.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return (int) e;
+    pl->has_table = true;
+    pl->has_inv = inv_ok;
+    return NTT_OK;
+}
+
+int ntt_make_table(ntt_plan_t pl, int kind, uint64_t g, void *host_T) {
+    if (!pl || !host_T) return NTT_E_ARG;
+    const uint64_t N = 1ull << pl->logn;
+    std::vector<uint64_t> T;
+    if (kind < 0 || kind > 2 || !make_table(kind, pl->logn, pl->p, g, T)) return NTT_E_ARG;
+    for (uint64_t i = 0; i < N; i++) {
+        if (pl->word_bytes == 4) ((uint32_t *) host_T)[i] = (uint32_t) T[i];
+        else ((uint64_t *) host_T)[i] = T[i];
+    }
+    return NTT_OK;
+}
+
+int ntt_make_roots(ntt_plan_t pl, uint64_t g, void *host_T) { return ntt_make_table(pl, 0, g, host_T); }
+
+int64_t ntt_plan_info(ntt_plan_t pl, int what) {
+    if (!pl) return NTT_E_ARG;
+    switch (what) {
+        case 0: return pl->logn;
+        case 1: return pl->word_bytes;
+        case 2: return pl->device;
+        case 3: return (int64_t) pl->passes.size();
+        case 4: return pl->has_inv ? 1 : 0;
+        default: return NTT_E_ARG;
+    }
+}
+
+int ntt_forward(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int out_layout, void *stream) {
+    int rc = check_io(pl, d_in, d_out, batch);
+    if (rc) return rc;
+    if (!pl->has_table) return NTT_E_NOTABLE;
+    if (out_layout != NTT_LAYOUT_NATURAL && out_layout != NTT_LAYOUT_AIE_BLOCK16) return NTT_E_ARG;
+    if (out_layout == NTT_LAYOUT_AIE_BLOCK16 && pl->logn < 4) return NTT_E_LAYOUT;
+    if (batch == 0) return NTT_OK;
+    DeviceGuard g(pl->device);
+    if (g.err != hipSuccess) return (int) g.err;
+    return run_forward(pl, d_in, d_out, batch, out_layout, (hipStream_t) stream);
+}
+
+int ntt_inverse(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int in_layout, int scale,
+                void *stream) {
+    int rc = check_io(pl, d_in, d_out, batch);
+    if (rc) return rc;
+    if (!pl->has_table) return NTT_E_NOTABLE;
+    if (!pl->has_inv) return NTT_E_NOTINVERTIBLE;
+    if (in_layout != NTT_LAYOUT_NATURAL && in_layout != NTT_LAYOUT_AIE_BLOCK16) return NTT_E_ARG;
+    if (in_layout == NTT_LAYOUT_AIE_BLOCK16 && pl->logn < 4) return NTT_E_LAYOUT;
+    if (batch == 0) return NTT_OK;
+    DeviceGuard g(pl->device);
+    if (g.err != hipSuccess) return (int) g.err;
+    return run_inverse(pl, d_in, d_out, batch, in_layout, scale, (hipStream_t) stream);
+}
+
+int ntt_pointwise_mul(ntt_plan_t pl, const void *d_a, const void *d_b, void *d_out, size_t batch,
+                      uint64_t scale, void *stream) {
+    int rc = check_io(pl, d_a, d_b, batch);
+    if (rc) return rc;
+    if (!d_out || ((uintptr_t) d_out & 15u)) return NTT_E_ARG;
+    if (scale >= pl->p) return NTT_E_RANGE;
+    if (batch == 0) return NTT_OK;
+    DeviceGuard g(pl->device);
+    if (g.err != hipSuccess) return (int) g.err;
+    const size_t count = batch << pl->logn;
+    hipError_t e = pl->word_bytes == 8
+                       ? ntt::launch_pointwise_gl(d_a, d_b, d_out, count, scale, (hipStream_t) stream)
+                       : ntt::launch_pointwise_m32(d_a, d_b, d_out, count, (uint32_t) pl->p, pl->pinv,
+                                                   pl->r2, (uint32_t) scale, (hipStream_t) stream);
+    return (int) e;
+}
+
+int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, size_t batch, void *stream) {
+    int rc = check_io(pl, d_a, d_b, batch);
+    if (rc) return rc;
+    if (!d_out || ((uintptr_t) d_out & 15u)) return NTT_E_ARG;
+    if (!pl->has_table) return NTT_E_NOTABLE;
+    if (!pl->has_inv) return NTT_E_NOTINVERTIBLE;
+    if (batch == 0) return NTT_OK;
+    DeviceGuard g(pl->device);
+    if (g.err != hipSuccess) return (int) g.err;
+    hipStream_t s = (hipStream_t) stream;
+    // With the Longa-Naehrig psi^-1 table the forward negacyclic NTT is the UNSCALED
+    // inverse network and the inverse negacyclic NTT is N^-1 * forward network
+    // (SURVEY F6-ii), so  c = Fwd( InvU(a) . InvU(b) . N^-1 ).
+    rc = run_inverse(pl, d_a, d_a, batch, NTT_LAYOUT_NATURAL, 0, s);
+    if (rc) return rc;
+    rc = run_inverse(pl, d_b, d_b, batch, NTT_LAYOUT_NATURAL, 0, s);
+    if (rc) return rc;
+    const size_t count = batch << pl->logn;
+    hipError_t e = pl->word_bytes == 8
+                       ? ntt::launch_pointwise_gl(d_a, d_b, d_out, count, pl->ninv_plain, s)
+                       : ntt::launch_pointwise_m32(d_a, d_b, d_out, count, (uint32_t) pl->p, pl->pinv,
+                                                   pl->r2, (uint32_t) pl->ninv_plain, s);
+    if (e != hipSuccess) return (int) e;
+    return run_forward(pl, d_out, d_out, batch, NTT_LAYOUT_NATURAL, s);
+}
+
+int ntt_forward_stages(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int stage, void *stream) {
+    int rc = check_io(pl, d_in, d_out, batch);
+    if (rc) return rc;
+    if (!pl->has_table) return NTT_E_NOTABLE;
+    if (stage < 0 || stage >= pl->logn) return NTT_E_ARG;
+    if (batch == 0) return NTT_OK;
+    DeviceGuard g(pl->device);
+    if (g.err != hipSuccess) return (int) g.err;
+    hipStream_t s = (hipStream_t) stream;
+    if (d_in != d_out) {
+        hipError_t e = hipMemcpyAsync(d_out, d_in, (batch << pl->logn) * pl->word_bytes,
+                                      hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int) e;
+    }
+    for (int st = 0; st <= stage; st++) {
+        hipError_t e = pl->word_bytes == 8
+                           ? ntt::launch_stage_gl(d_out, pl->d_tw_fwd, pl->logn, st, batch, s)
+                           : ntt::launch_stage_m32(d_out, pl->d_tw_fwd, pl->logn, st, batch,
+                                                   (uint32_t) pl->p, pl->pinv, pl->r2, s);
+        if (e != hipSuccess) return (int) e;
+    }
+    return NTT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,421 @@
+// pass.h -- one HBM pass of the butterfly network: a group of consecutive stages
+// executed on a workgroup-resident tile, radix-16 register rounds exchanged
+// through LDS.
+//
+// What it replaces (file:line under the reference tree):
+//   src/aie_core.cc:189-361  ntt_stage0_to_Nminus5  tile-local stages on a
+//                            contiguous slab  -> CONTIG pass (s0 == 0)
+//   src/aie_core.cc:161-187  ntt_1stage             cross-tile stage with one
+//                            twiddle per block      -> column pass (s0 > 0)
+//   src/aie_core.cc:104-125  ntt_stage_parallel8    the butterfly
+//   src/aie_core.cc:133-159  swap_buff / write_back not needed: the tile swaps
+//                            become the index rule of store_direct()
+//   src/aie2.py:166-315      the per-tile stage schedule -> run_pass()
+// and the network definition itself, src/test.cpp:34-60.
+//
+// Index model.  Word j of a polynomial (N = 2^n words) is split as
+//     j = (hi << (s0 + LOG_M)) | (mid << s0) | lo
+// A pass runs stages s0 .. s0+LOG_M-1, i.e. the size-M network over `mid` for
+// every (hi, lo).  The twiddle of the butterfly at stage s = s0 + m is
+//     T[(N >> (s+1)) + (j >> (s+1))]        (src/test.cpp:41-45: roots_rev[h+i])
+// which depends on (hi, mid >> (m+1)) only -- never on lo, never on the
+// polynomial.  So a workgroup fixes (hi, lo-tile), keeps its twiddles in
+// registers and streams polynomials of the batch through them.
+//
+// A thread owns E = 16 words whose `mid` differ in a 4-bit window [b0, b0+4);
+// a round runs up to 4 stages on them in registers, then the tile is exchanged
+// in place through padded LDS and the next round uses the next window.
+//
+// The body is written as phases over a thread context so that the very same
+// code runs on the GPU (one context per lane, __syncthreads between phases) and
+// in the host index model (tests/emu: all 256 contexts stepped phase by phase).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "field.h"
+
+namespace ntt {
+
+constexpr int LOG_NT = 8;
+constexpr int NT = 1 << LOG_NT;  // threads per workgroup = 4 waves of 64
+
+enum { LAYOUT_NATURAL = 0, LAYOUT_AIE_BLOCK16 = 1 };
+
+// src/test.cpp:69-71 ans_order as an index rule: swap the bits inside each 2-bit
+// half of the 4-bit block index (1<->2, 4<->8, 5<->10, 6<->9, 7<->11, 13<->14).
+NTT_HD uint32_t aie_block16(uint32_t b) { return ((b & 5u) << 1) | ((b >> 1) & 5u); }
+
+template <int I, int N, class Fn>
+NTT_HD void static_for(Fn &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <class F_, int LOG_M_, int LOG_C_, bool CONTIG_, bool INV_, bool PRELOAD_ = true>
+struct PassCfg {
+    using F = F_;
+    using W = typename F::W;
+    static constexpr int LOG_M = LOG_M_;  // stages in this pass
+    static constexpr int LOG_C = LOG_C_;  // log2 columns (lo values) per tile; 0 when CONTIG
+    static constexpr bool CONTIG = CONTIG_;
+    static constexpr bool INV = INV_;
+    static constexpr bool PRELOAD = PRELOAD_;
+    static constexpr int LOG_E = LOG_M < 4 ? LOG_M : 4;
+    static constexpr int E = 1 << LOG_E;  // words per thread
+    static constexpr int M = 1 << LOG_M;
+    static constexpr int C = 1 << LOG_C;
+    static constexpr int LOG_Q = LOG_M - LOG_E;  // threads along mid
+    static constexpr int LOG_U = LOG_NT + LOG_E - LOG_M - LOG_C;  // units per workgroup
+    static_assert(LOG_U >= 0, "tile does not fit a 256-thread workgroup");
+    static_assert(!CONTIG || LOG_C == 0, "contiguous pass has no column dimension");
+    static constexpr int R = (LOG_M + LOG_E - 1) / LOG_E;  // register rounds
+    static constexpr int VW = 16 / (int) sizeof(W);        // words per 16-byte chunk
+    static constexpr int TILE_WORDS = NT * E;
+    // one 16-byte pad per E words keeps 16-byte alignment and skews the lanes
+    static constexpr int LDS_WORDS = TILE_WORDS + (TILE_WORDS >> LOG_E) * VW;
+
+    static constexpr int win(int r) { return r * LOG_E > LOG_M - LOG_E ? LOG_M - LOG_E : r * LOG_E; }
+    static constexpr int stage_lo(int r) { return r * LOG_E; }
+    static constexpr int stage_hi(int r) { return (r + 1) * LOG_E > LOG_M ? LOG_M : (r + 1) * LOG_E; }
+    // global loads / stores straight between HBM and the round registers are
+    // coalesced when lanes run along columns (column pass) or along the low mid
+    // bits (high window); otherwise the tile is staged linearly through LDS.
+    static constexpr bool DIRECT_LOAD = !CONTIG || R == 1 || INV;
+    static constexpr bool DIRECT_STORE = !CONTIG || R == 1 || !INV;
+
+    static NTT_HD uint32_t lds_index(uint32_t lin) { return lin + ((lin >> LOG_E) * VW); }
+};
+
+template <class Cfg>
+struct PassArgs {
+    using W = typename Cfg::W;
+    const W *in;
+    W *out;
+    const W *tw;  // device table for this direction (T or T^-1), table form
+    typename Cfg::F field;
+    int n;   // log2 N
+    int s0;  // first stage of the pass
+    uint32_t batch;
+    int ppw;     // polynomials streamed per workgroup along blockIdx.y
+    int log_ul;  // unit split: lo-tiles, hi values, polynomials (sum = LOG_U)
+    int log_uh;
+    int log_up;
+    int layout;    // transform-domain layout; honoured by the pass holding the top stage
+    int do_scale;  // inverse: multiply by `scale` (N^-1, table form) after the last round
+    W scale;
+};
+
+template <class Cfg>
+struct Ctx {
+    using W = typename Cfg::W;
+    W x[Cfg::E];
+    W tw[Cfg::R][Cfg::E > 1 ? Cfg::E - 1 : 1];
+    uint32_t tid, bx, by;
+    uint32_t q, hi;          // mid-thread index, hi value (twiddle addressing)
+    uint32_t up;             // polynomial sub-index inside the workgroup
+    uint32_t lane_ld, lane_st;       // lane part of the global word index (first / last round)
+    uint32_t lds_base[Cfg::R];       // padded LDS index of element 0 of each round
+    bool active;
+};
+
+// ---- index helpers -----------------------------------------------------------
+// Every address is split into a wave-uniform part (block ids, iteration, element
+// number: lives in SGPRs), ONE loop-invariant lane part, and a compile-time
+// element offset, so the batch loop carries a handful of address registers
+// instead of one per element.
+
+// padded LDS offset of element e in round r relative to lds_base[r]; exact because
+// the element field and the base occupy disjoint bits (no carries into the pad term)
+template <class Cfg>
+constexpr uint32_t lds_elem_off(int r, int e) {
+    const uint32_t lin = (uint32_t) e << (Cfg::win(r) + Cfg::LOG_C);
+    return lin + ((lin >> Cfg::LOG_E) * Cfg::VW);
+}
+
+// lane part of the word index for the round whose window starts at b0
+template <class Cfg>
+NTT_HD uint32_t lane_word(const PassArgs<Cfg> &a, int b0, uint32_t q, uint32_t c, uint32_t u_l,
+                          uint32_t u_h, uint32_t up) {
+    const uint32_t q_lo = q & ((1u << b0) - 1u);
+    const uint32_t q_hi = q >> b0;
+    return (up << a.n) + (u_h << (a.s0 + Cfg::LOG_M)) + (q_hi << (b0 + Cfg::LOG_E + a.s0)) +
+           (q_lo << a.s0) + (u_l << Cfg::LOG_C) + c;
+}
+
+// uniform part of the word index: workgroup tile origin + polynomial group of iteration `it`
+template <class Cfg>
+NTT_HD size_t uniform_word(const Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
+    const int log_ltb = Cfg::CONTIG ? 0 : a.s0 - Cfg::LOG_C - a.log_ul;
+    const uint32_t ltb = Cfg::CONTIG ? 0u : (c.bx & ((1u << log_ltb) - 1u));
+    const uint32_t hb = Cfg::CONTIG ? c.bx : (c.bx >> log_ltb);
+    const size_t pg = (size_t) c.by * (uint32_t) a.ppw + (uint32_t) it;
+    return ((size_t) hb << (a.log_uh + a.s0 + Cfg::LOG_M)) + ((size_t) ltb << (a.log_ul + Cfg::LOG_C)) +
+           (pg << (a.log_up + a.n));
+}
+
+// ---- phases -------------------------------------------------------------------
+template <class Cfg, int r>
+NTT_HD void load_twiddles(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
+    constexpr int b0 = Cfg::win(r);
+    const uint32_t q_hi = (b0 + Cfg::LOG_E >= Cfg::LOG_M) ? 0u : (c.q >> b0);
+    static_for<Cfg::stage_lo(r), Cfg::stage_hi(r)>([&](auto mm) {
+        constexpr int m = decltype(mm)::value;
+        constexpr int t = m - b0;
+        constexpr int cnt = Cfg::E >> (t + 1);
+        constexpr int off = Cfg::E - (Cfg::E >> t);
+        const int s = a.s0 + m;
+        const uint32_t base = (1u << (a.n - s - 1)) + (c.hi << (Cfg::LOG_M - m - 1)) +
+                              (q_hi << (Cfg::LOG_E - t - 1));
+#pragma unroll
+        for (int k = 0; k < cnt; ++k) c.tw[r][off + k] = a.tw[base + k];
+    });
+}
+
+template <class Cfg>
+NTT_HD void phase_init(Ctx<Cfg> &c, const PassArgs<Cfg> &a, uint32_t tid, uint32_t bx, uint32_t by) {
+    c.tid = tid;
+    c.bx = bx;
+    c.by = by;
+    const uint32_t col = tid & (Cfg::C - 1);
+    c.q = (tid >> Cfg::LOG_C) & ((1u << Cfg::LOG_Q) - 1u);
+    const uint32_t u = Cfg::LOG_U == 0 ? 0u : (tid >> (Cfg::LOG_C + Cfg::LOG_Q));
+    const uint32_t u_l = u & ((1u << a.log_ul) - 1u);
+    const uint32_t u_h = (u >> a.log_ul) & ((1u << a.log_uh) - 1u);
+    c.up = u >> (a.log_ul + a.log_uh);
+    // blockIdx.x enumerates (lo-tile block, hi block), lo-tile fastest
+    const int log_ltb = Cfg::CONTIG ? 0 : a.s0 - Cfg::LOG_C - a.log_ul;
+    const uint32_t hb = Cfg::CONTIG ? bx : (bx >> log_ltb);
+    c.hi = (hb << a.log_uh) | u_h;
+    constexpr int FIRST = Cfg::INV ? Cfg::R - 1 : 0;
+    constexpr int LAST = Cfg::INV ? 0 : Cfg::R - 1;
+    c.lane_ld = lane_word<Cfg>(a, Cfg::win(FIRST), c.q, col, u_l, u_h, c.up);
+    c.lane_st = lane_word<Cfg>(a, Cfg::win(LAST), c.q, col, u_l, u_h, c.up);
+    static_for<0, Cfg::R>([&](auto rr) {
+        constexpr int r = decltype(rr)::value;
+        constexpr int b0 = Cfg::win(r);
+        const uint32_t q_lo = c.q & ((1u << b0) - 1u);
+        const uint32_t q_hi = c.q >> b0;
+        const uint32_t mid0 = (q_hi << (b0 + Cfg::LOG_E)) | q_lo;
+        c.lds_base[r] = Cfg::lds_index((((u << Cfg::LOG_M) | mid0) << Cfg::LOG_C) | col);
+    });
+    if constexpr (Cfg::PRELOAD) {
+        static_for<0, Cfg::R>([&](auto rr) { load_twiddles<Cfg, decltype(rr)::value>(c, a); });
+    }
+}
+
+template <class Cfg>
+NTT_HD void phase_begin_iter(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
+    const uint32_t poly = ((c.by * (uint32_t) a.ppw + (uint32_t) it) << a.log_up) | c.up;
+    c.active = poly < a.batch;
+}
+
+// element number as seen by the transform-domain layout: in the pass that holds the
+// top stage the 4-bit window of the outermost round IS the 16-block index of
+// src/test.cpp:69-71, so the block permutation is a compile-time renumbering.
+template <class Cfg>
+NTT_HD uint32_t elem_eff(const PassArgs<Cfg> &a, int e, bool want) {
+    if constexpr (Cfg::LOG_E == 4) {
+        const bool perm = want && a.layout == LAYOUT_AIE_BLOCK16 && (a.s0 + Cfg::LOG_M == a.n);
+        return perm ? aie_block16((uint32_t) e) : (uint32_t) e;
+    } else {
+        return (uint32_t) e;
+    }
+}
+
+template <class Cfg, int r>
+NTT_HD void phase_load_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
+    using W = typename Cfg::W;
+    const W *ubase = a.in + uniform_word<Cfg>(c, a, it);
+#pragma unroll
+    for (int e = 0; e < Cfg::E; ++e) {
+        const size_t eo = (size_t) elem_eff<Cfg>(a, e, Cfg::INV) << (Cfg::win(r) + a.s0);
+        c.x[e] = c.active ? (ubase + eo)[c.lane_ld] : (W) 0;
+    }
+}
+
+template <class Cfg, int r>
+NTT_HD void phase_store_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
+    using W = typename Cfg::W;
+    W *ubase = a.out + uniform_word<Cfg>(c, a, it);
+    if (!c.active) return;
+#pragma unroll
+    for (int e = 0; e < Cfg::E; ++e) {
+        const size_t eo = (size_t) elem_eff<Cfg>(a, e, !Cfg::INV) << (Cfg::win(r) + a.s0);
+        (ubase + eo)[c.lane_st] = c.x[e];
+    }
+}
+
+template <class W, int V>
+struct alignas(sizeof(W) * V) Chunk {
+    W v[V];
+};
+
+// CONTIG only.  The workgroup's units are consecutive hi values of one polynomial
+// or, when a polynomial has fewer units than the workgroup, whole consecutive
+// polynomials: either way TILE_WORDS contiguous words of the [batch][N] buffer.
+// Move them between HBM and LDS in 16-byte chunks, lanes along consecutive chunks.
+template <class Cfg, bool TO_LDS>
+NTT_HD void phase_linear(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *lds, int it) {
+    using W = typename Cfg::W;
+    constexpr int V = Cfg::E < Cfg::VW ? Cfg::E : Cfg::VW;  // words per chunk
+    constexpr int ITER = Cfg::E / V;
+    using Ch = Chunk<W, V>;
+    const size_t tile0 = uniform_word<Cfg>(c, a, it);
+    const uint32_t pg0 = (c.by * (uint32_t) a.ppw + (uint32_t) it) << a.log_up;
+    const uint32_t lbase = Cfg::lds_index(c.tid * V);
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        constexpr uint32_t STEP = NT * V;  // multiple of E: pad term is linear in i
+        const uint32_t lin = (uint32_t) i * STEP + c.tid * V;
+        // unit of this chunk -> its polynomial (ragged batch tail)
+        const uint32_t u_p = (lin >> Cfg::LOG_M) >> a.log_uh;
+        const bool active = (pg0 | u_p) < a.batch;
+        const uint32_t l = lbase + (uint32_t) i * (STEP + (STEP >> Cfg::LOG_E) * Cfg::VW);
+        if constexpr (TO_LDS) {
+            Ch v;
+            if (active) {
+                v = *reinterpret_cast<const Ch *>(a.in + tile0 + lin);
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; ++k) v.v[k] = 0;
+            }
+            *reinterpret_cast<Ch *>(lds + l) = v;
+        } else {
+            if (active) *reinterpret_cast<Ch *>(a.out + tile0 + lin) = *reinterpret_cast<const Ch *>(lds + l);
+        }
+    }
+}
+
+template <class Cfg, int r>
+NTT_HD void phase_lds_read(Ctx<Cfg> &c, const typename Cfg::W *lds) {
+    const typename Cfg::W *p = lds + c.lds_base[r];
+#pragma unroll
+    for (int e = 0; e < Cfg::E; ++e) c.x[e] = p[lds_elem_off<Cfg>(r, e)];
+}
+
+template <class Cfg, int r>
+NTT_HD void phase_lds_write(Ctx<Cfg> &c, typename Cfg::W *lds) {
+    typename Cfg::W *p = lds + c.lds_base[r];
+#pragma unroll
+    for (int e = 0; e < Cfg::E; ++e) p[lds_elem_off<Cfg>(r, e)] = c.x[e];
+}
+
+// The butterflies of round r (src/aie_core.cc:104-125 ntt_stage_parallel8;
+// src/test.cpp:46-50).  Forward: (x, y) -> (x + y, (x - y) * T), stages ascending.
+// Inverse: (u, v) -> (u + v/T, u - v/T), stages descending.
+template <class Cfg, int r>
+NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
+    using W = typename Cfg::W;
+    constexpr int b0 = Cfg::win(r);
+    constexpr int lo = Cfg::stage_lo(r), hi = Cfg::stage_hi(r);
+    if constexpr (!Cfg::PRELOAD) load_twiddles<Cfg, r>(c, a);
+    const typename Cfg::F &f = a.field;
+    static_for<0, hi - lo>([&](auto kk) {
+        constexpr int m = Cfg::INV ? (hi - 1 - decltype(kk)::value) : (lo + decltype(kk)::value);
+        constexpr int t = m - b0;
+        constexpr int off = Cfg::E - (Cfg::E >> t);
+#pragma unroll
+        for (int e = 0; e < Cfg::E; ++e) {
+            if (e & (1 << t)) continue;
+            const int e1 = e | (1 << t);
+            const W T = c.tw[r][off + (e >> (t + 1))];
+            const W x = c.x[e], y = c.x[e1];
+            if constexpr (!Cfg::INV) {
+                c.x[e] = f.add(x, y);
+                c.x[e1] = f.mul(f.sub(x, y), T);
+            } else {
+                const W w = f.mul(y, T);
+                c.x[e] = f.add(x, w);
+                c.x[e1] = f.sub(x, w);
+            }
+        }
+    });
+}
+
+template <class Cfg>
+NTT_HD void phase_scale(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
+    if (!a.do_scale) return;
+#pragma unroll
+    for (int e = 0; e < Cfg::E; ++e) c.x[e] = a.field.mul(c.x[e], a.scale);
+}
+
+// ---- the schedule (src/aie2.py:166-315, collapsed) ----------------------------
+// Exec supplies: each(fn) -- run fn(ctx) for this lane (GPU) or for all 256
+// contexts (host model); sync() -- workgroup barrier; lds() -- the tile.
+template <class Cfg, class Exec>
+NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
+    using C = Ctx<Cfg>;
+    constexpr int R = Cfg::R;
+    constexpr int FIRST = Cfg::INV ? R - 1 : 0;
+    constexpr int LAST = Cfg::INV ? 0 : R - 1;
+    constexpr bool ANY_LDS = R > 1 || !Cfg::DIRECT_LOAD || !Cfg::DIRECT_STORE;
+    ex.init(a);
+    for (int it = 0; it < a.ppw; ++it) {
+        ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, it); });
+        if constexpr (Cfg::DIRECT_LOAD) {
+            ex.each([&](C &c) { phase_load_direct<Cfg, FIRST>(c, a, it); });
+        } else {
+            ex.each([&](C &c) { phase_linear<Cfg, true>(c, a, ex.lds(), it); });
+            ex.sync();
+            ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, ex.lds()); });
+        }
+        static_for<0, R>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            constexpr int r = Cfg::INV ? R - 1 - k : k;
+            ex.each([&](C &c) { phase_compute<Cfg, r>(c, a); });
+            if constexpr (k < R - 1) {
+                constexpr int rn = Cfg::INV ? r - 1 : r + 1;
+                ex.each([&](C &c) { phase_lds_write<Cfg, r>(c, ex.lds()); });
+                ex.sync();
+                ex.each([&](C &c) { phase_lds_read<Cfg, rn>(c, ex.lds()); });
+            }
+        });
+        if constexpr (Cfg::INV) ex.each([&](C &c) { phase_scale<Cfg>(c, a); });
+        if constexpr (Cfg::DIRECT_STORE) {
+            ex.each([&](C &c) { phase_store_direct<Cfg, LAST>(c, a, it); });
+        } else {
+            ex.each([&](C &c) { phase_lds_write<Cfg, LAST>(c, ex.lds()); });
+            ex.sync();
+            ex.each([&](C &c) { phase_linear<Cfg, false>(c, a, ex.lds(), it); });
+        }
+        if constexpr (ANY_LDS) {
+            if (it + 1 < a.ppw) ex.sync();  // next iteration rewrites the tile
+        }
+    }
+}
+
+// ---- launch geometry shared by host planner and host model ---------------------
+struct PassGeom {
+    int log_ul, log_uh, log_up;
+    uint32_t grid_x, grid_y;
+    int ppw;
+};
+
+// n = log2 N, pass covers stages [s0, s0 + log_m); log_c columns; log_u units per WG
+inline PassGeom pass_geometry(int n, int s0, int log_m, int log_c, int log_u, bool contig,
+                              uint64_t batch, uint32_t target_wgs) {
+    PassGeom g;
+    const int log_h = n - s0 - log_m;              // hi values per polynomial
+    const int log_lt = contig ? 0 : s0 - log_c;    // lo tiles per (poly, hi)
+    g.log_ul = log_u < log_lt ? log_u : log_lt;
+    int rem = log_u - g.log_ul;
+    g.log_uh = rem < log_h ? rem : log_h;
+    g.log_up = rem - g.log_uh;
+    g.grid_x = 1u << ((log_lt - g.log_ul) + (log_h - g.log_uh));
+    const uint64_t poly_groups = (batch + (1ull << g.log_up) - 1) >> g.log_up;
+    // stream several polynomials through one workgroup (twiddles stay in registers)
+    // but keep at least target_wgs workgroups in flight
+    uint64_t ppw = 1;
+    while (ppw < 64 && (uint64_t) g.grid_x * ((poly_groups + 2 * ppw - 1) / (2 * ppw)) >= target_wgs) ppw *= 2;
+    g.ppw = (int) ppw;
+    uint64_t gy = (poly_groups + ppw - 1) / ppw;
+    g.grid_y = (uint32_t) gy;
+    return g;
+}
+
+}  // namespace ntt

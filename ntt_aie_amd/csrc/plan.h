@@ -1,0 +1,138 @@
+// plan.h -- host-only planning and table preparation shared by the C-ABI
+// (ntt_api.hip) and the host index model (tests/emu).  No HIP types here.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+namespace ntt {
+namespace host {
+
+using u128 = unsigned __int128;
+
+constexpr uint64_t GOLDILOCKS = 0xFFFFFFFF00000001ULL;
+constexpr int MAX_CONTIG_LOG_M = 12;  // 4096 words per workgroup tile
+constexpr int MIN_COL_LOG_M = 4;
+constexpr int MAX_COL_LOG_M = 8;
+
+struct PassDesc {
+    bool contig;
+    int s0;
+    int log_m;
+};
+
+inline uint64_t mulmod(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t) (((u128) a * b) % p); }
+
+inline uint64_t powmod(uint64_t x, uint64_t e, uint64_t p) {
+    uint64_t r = 1 % p;
+    x %= p;
+    while (e) {
+        if (e & 1) r = mulmod(r, x, p);
+        x = mulmod(x, x, p);
+        e >>= 1;
+    }
+    return r;
+}
+
+inline uint64_t bitrev(uint64_t x, int bits) {
+    uint64_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1ULL) << (bits - 1 - i);
+    return r;
+}
+
+// Split logn stages into HBM passes: one contiguous pass of <= 12 stages (tile =
+// 4096 words in LDS) followed by column passes of 4..8 stages (256 rows x 16 columns).
+inline std::vector<PassDesc> plan_passes(int n) {
+    std::vector<PassDesc> v;
+    if (n <= MAX_CONTIG_LOG_M) {
+        v.push_back({true, 0, n});
+        return v;
+    }
+    const int extra = (n - MAX_CONTIG_LOG_M + MAX_COL_LOG_M - 1) / MAX_COL_LOG_M;
+    const int P = 1 + extra;
+    int first = (n + P - 1) / P;
+    if (first < n - MAX_COL_LOG_M * extra) first = n - MAX_COL_LOG_M * extra;
+    if (first > MAX_CONTIG_LOG_M) first = MAX_CONTIG_LOG_M;
+    v.push_back({true, 0, first});
+    int rest = n - first, s0 = first;
+    for (int i = 0; i < extra; i++) {
+        int m = (rest + (extra - i) - 1) / (extra - i);
+        v.push_back({false, s0, m});
+        s0 += m;
+        rest -= m;
+    }
+    return v;
+}
+
+// Montgomery constants of FieldM32
+inline uint32_t mont_pinv(uint32_t p) {
+    uint32_t inv = p;  // Newton: inv *= 2 - p*inv; 3 correct bits double each step
+    for (int i = 0; i < 5; i++) inv *= 2u - p * inv;
+    return inv;
+}
+inline uint32_t mont_r2(uint32_t p) { return (uint32_t) ((((u128) 1) << 64) % p); }
+
+// value -> the form the kernels keep twiddles in
+inline uint64_t to_table_form(uint64_t t, uint64_t p, int word_bytes) {
+    return word_bytes == 4 ? (uint64_t) ((((u128) t) << 32) % p) : t;
+}
+
+// Tinv[i] = T[i]^-1 for i >= 1 by batch inversion; false when some T[i] == 0
+inline bool invert_table(const std::vector<uint64_t> &T, uint64_t p, std::vector<uint64_t> &Ti) {
+    const size_t N = T.size();
+    Ti.assign(N, 0);
+    for (size_t i = 1; i < N; i++)
+        if (T[i] == 0) return false;
+    std::vector<uint64_t> pre(N);
+    uint64_t acc = 1;
+    for (size_t i = 1; i < N; i++) {
+        pre[i] = acc;
+        acc = mulmod(acc, T[i], p);
+    }
+    uint64_t inv = powmod(acc, p - 2, p);
+    for (size_t i = N; i-- > 1;) {
+        Ti[i] = mulmod(inv, pre[i], p);
+        inv = mulmod(inv, T[i], p);
+    }
+    Ti[0] = 1;
+    return true;
+}
+
+// table rules: kind 0 = src/test.cpp:27-32 + :138 (make_roots); 1 = cyclic bit-reversed;
+// 2 = Longa-Naehrig psi^-1 bit-reversed.  false when N does not divide the order.
+inline bool make_table(int kind, int logn, uint64_t p, uint64_t g, std::vector<uint64_t> &T) {
+    const uint64_t N = 1ull << logn;
+    T.assign(N, 0);
+    if (kind == 0) {
+        const uint64_t w = powmod(g, (p - 1) / N, p);
+        T[0] = 1 % p;
+        for (uint64_t i = 1; i < N; i++) T[i] = mulmod(T[i - 1], w, p);
+        return true;
+    }
+    if (kind == 1) {
+        if ((p - 1) % N) return false;
+        const uint64_t w = powmod(g, (p - 1) / N, p);
+        std::vector<uint64_t> pw(N);
+        pw[0] = 1;
+        for (uint64_t i = 1; i < N; i++) pw[i] = mulmod(pw[i - 1], w, p);
+        T[0] = 1;
+        int lh = 0;
+        for (uint64_t h = 1; h < N; h <<= 1, lh++)
+            for (uint64_t i = 0; i < h; i++) T[h + i] = pw[(bitrev(i, lh) * (N / (2 * h))) % N];
+        return true;
+    }
+    if (kind == 2) {
+        if ((p - 1) % (2 * N)) return false;
+        const uint64_t psi = powmod(g, (p - 1) / (2 * N), p);
+        const uint64_t psi_inv = powmod(psi, p - 2, p);
+        std::vector<uint64_t> pw(N);
+        pw[0] = 1;
+        for (uint64_t i = 1; i < N; i++) pw[i] = mulmod(pw[i - 1], psi_inv, p);
+        for (uint64_t k = 0; k < N; k++) T[k] = pw[bitrev(k, logn)];
+        return true;
+    }
+    return false;
+}
+
+}  // namespace host
+}  // namespace ntt

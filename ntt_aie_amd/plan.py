@@ -1,0 +1,158 @@
+"""Python host of the MI355X NTT engine.
+
+Mirrors the reference host procedure (src/test.cpp:115-190): make the twiddle
+table with the reference's rule, hand over (input, root, output) buffers, launch,
+wait.  torch is used only for device memory and streams; every transform goes
+through the C-ABI in libntt_hip.so (ntt_aie_amd/_lib.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import LAYOUT_AIE_BLOCK16, LAYOUT_NATURAL, check
+
+GOLDILOCKS = 0xFFFFFFFF00000001
+
+
+def _np_dtype(word_bytes: int):
+    return np.uint32 if word_bytes == 4 else np.uint64
+
+
+def _torch_dtype(word_bytes: int):
+    # torch tensors are plain device memory here: signed types carry the same bits
+    return torch.int32 if word_bytes == 4 else torch.int64
+
+
+def to_device(a: np.ndarray, device) -> torch.Tensor:
+    """Host words -> device buffer with the same bit pattern."""
+    a = np.ascontiguousarray(a)
+    signed = a.view(np.int32 if a.dtype.itemsize == 4 else np.int64)
+    return torch.from_numpy(signed).to(device)
+
+
+def to_host(t: torch.Tensor) -> np.ndarray:
+    a = t.detach().cpu().contiguous().numpy()
+    return a.view(np.uint32 if a.dtype.itemsize == 4 else np.uint64)
+
+
+class NTTPlan:
+    """One (logn, p, word size) transform plan on one GPU.
+
+    The plan owns the device copies of the twiddle table ("root" buffer,
+    src/test.cpp:119-120) and of its inverse; data buffers stay caller-owned.
+    """
+
+    def __init__(self, logn: int, p: int, word_bytes: int | None = None, device: int | None = None):
+        if word_bytes is None:
+            word_bytes = 8 if p >= (1 << 32) else 4
+        if device is None:
+            device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        self.logn, self.n, self.p, self.word_bytes, self.device = logn, 1 << logn, p, word_bytes, device
+        self._h = C.c_void_p()
+        check(_lib.lib().ntt_plan_create(C.byref(self._h), logn, p, word_bytes, device), "ntt_plan_create")
+        self.table: np.ndarray | None = None
+
+    def close(self) -> None:
+        if self._h:
+            _lib.lib().ntt_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tables (host side, like the reference's make_roots) -----------------
+    def make_roots(self, g: int) -> np.ndarray:
+        """src/test.cpp:27-32 + :138: T[0]=1, T[i]=T[i-1]*g^((p-1)/N) mod p."""
+        return self.make_table(0, g)
+
+    def make_table(self, kind: int, g: int) -> np.ndarray:
+        T = np.empty(self.n, dtype=_np_dtype(self.word_bytes))
+        check(_lib.lib().ntt_make_table(self._h, kind, g, T.ctypes.data), "ntt_make_table")
+        return T
+
+    def set_twiddles(self, T: np.ndarray) -> None:
+        T = np.ascontiguousarray(T, dtype=_np_dtype(self.word_bytes))
+        if T.shape != (self.n,):
+            raise ValueError("twiddle table must have N = %d words" % self.n)
+        check(_lib.lib().ntt_plan_set_twiddles(self._h, T.ctypes.data), "ntt_plan_set_twiddles")
+        self.table = T
+
+    @property
+    def hbm_passes(self) -> int:
+        return int(_lib.lib().ntt_plan_info(self._h, 3))
+
+    @property
+    def has_inverse(self) -> bool:
+        return bool(_lib.lib().ntt_plan_info(self._h, 4))
+
+    # ---- buffers ---------------------------------------------------------------
+    def empty(self, batch: int) -> torch.Tensor:
+        return torch.empty((batch, self.n), dtype=_torch_dtype(self.word_bytes),
+                           device=torch.device("cuda", self.device))
+
+    def _batch(self, *ts: torch.Tensor) -> int:
+        for t in ts:
+            if not t.is_cuda or t.device.index != self.device:
+                raise ValueError("buffer is not on cuda:%d" % self.device)
+            if not t.is_contiguous() or t.element_size() != self.word_bytes:
+                raise ValueError("buffer must be contiguous with %d-byte words" % self.word_bytes)
+            if t.numel() % self.n or t.numel() != ts[0].numel():
+                raise ValueError("buffer sizes must be equal multiples of N")
+        return ts[0].numel() // self.n
+
+    @staticmethod
+    def _stream(stream) -> int:
+        if stream is None:
+            stream = torch.cuda.current_stream()
+        return stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
+
+    # ---- transforms ------------------------------------------------------------
+    def forward(self, inp: torch.Tensor, out: torch.Tensor | None = None, layout: int = LAYOUT_NATURAL,
+                stream=None) -> torch.Tensor:
+        """The reference network (src/test.cpp:34-60) on every polynomial of `inp`."""
+        out = torch.empty_like(inp) if out is None else out
+        b = self._batch(inp, out)
+        check(_lib.lib().ntt_forward(self._h, inp.data_ptr(), out.data_ptr(), b, layout,
+                                     self._stream(stream)), "ntt_forward")
+        return out
+
+    def inverse(self, inp: torch.Tensor, out: torch.Tensor | None = None, layout: int = LAYOUT_NATURAL,
+                scale: bool = True, stream=None) -> torch.Tensor:
+        out = torch.empty_like(inp) if out is None else out
+        b = self._batch(inp, out)
+        check(_lib.lib().ntt_inverse(self._h, inp.data_ptr(), out.data_ptr(), b, layout, int(scale),
+                                     self._stream(stream)), "ntt_inverse")
+        return out
+
+    def pointwise_mul(self, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None,
+                      scale: int = 1, stream=None) -> torch.Tensor:
+        out = torch.empty_like(a) if out is None else out
+        n = self._batch(a, b, out)
+        check(_lib.lib().ntt_pointwise_mul(self._h, a.data_ptr(), b.data_ptr(), out.data_ptr(), n, scale,
+                                           self._stream(stream)), "ntt_pointwise_mul")
+        return out
+
+    def polymul_negacyclic(self, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None,
+                           stream=None) -> torch.Tensor:
+        """c = a*b mod (x^N + 1, p); needs a kind-2 table.  a and b are overwritten."""
+        out = a if out is None else out
+        n = self._batch(a, b, out)
+        check(_lib.lib().ntt_polymul_negacyclic(self._h, a.data_ptr(), b.data_ptr(), out.data_ptr(), n,
+                                                self._stream(stream)), "ntt_polymul_negacyclic")
+        return out
+
+    def forward_stages(self, inp: torch.Tensor, stage: int, out: torch.Tensor | None = None,
+                       stream=None) -> torch.Tensor:
+        """Stages 0..stage only (the reference's test_stage hook, src/test.cpp:55-58, 67)."""
+        out = torch.empty_like(inp) if out is None else out
+        b = self._batch(inp, out)
+        check(_lib.lib().ntt_forward_stages(self._h, inp.data_ptr(), out.data_ptr(), b, stage,
+                                            self._stream(stream)), "ntt_forward_stages")
+        return out

@@ -1,0 +1,214 @@
+// emu.cpp -- host index model of the pass kernels.
+//
+// TEST INFRASTRUCTURE.  Compiles the very same pass.h / field.h / plan.h the HIP
+// kernels are built from with g++ and steps all 256 thread contexts of every
+// workgroup phase by phase (the role __syncthreads() plays on the GPU), so the
+// index rules, the LDS exchange pattern, the pass planner and the modular
+// arithmetic can be checked against the oracle on a machine without a GPU.
+// It is not a CPU fallback: nothing in the product loads this library.
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../ntt_aie_amd/csrc/pass.h"
+#include "../../ntt_aie_amd/csrc/plan.h"
+
+using namespace ntt;
+using namespace ntt::host;
+
+namespace {
+
+constexpr int LOG_COLS = 4;  // keep equal to kernels.h
+
+template <class Cfg>
+struct EmuExec {
+    std::vector<Ctx<Cfg>> ctx;
+    std::vector<typename Cfg::W> tile;
+    uint32_t bx, by;
+    EmuExec() : ctx(NT), tile(Cfg::LDS_WORDS) {}
+    void init(const PassArgs<Cfg> &a) {
+        for (int t = 0; t < NT; t++) phase_init<Cfg>(ctx[t], a, (uint32_t) t, bx, by);
+    }
+    template <class Fn>
+    void each(Fn &&f) {
+        for (int t = 0; t < NT; t++) f(ctx[t]);
+    }
+    void sync() {}
+    typename Cfg::W *lds() { return tile.data(); }
+};
+
+struct Erased {
+    const void *in;
+    void *out;
+    const void *tw;
+    uint32_t p, pinv, r2;
+    int n, s0;
+    uint32_t batch;
+    int layout, do_scale;
+    uint64_t scale;
+    uint32_t target_wgs;
+};
+
+template <class F>
+F make_field(const Erased &e);
+template <>
+FieldGL make_field<FieldGL>(const Erased &) {
+    return FieldGL{};
+}
+template <>
+FieldM32 make_field<FieldM32>(const Erased &e) {
+    return FieldM32{e.p, e.pinv, e.r2};
+}
+
+template <class Cfg>
+int run_cfg(const Erased &e) {
+    using W = typename Cfg::W;
+    PassArgs<Cfg> a;
+    a.in = (const W *) e.in;
+    a.out = (W *) e.out;
+    a.tw = (const W *) e.tw;
+    a.field = make_field<typename Cfg::F>(e);
+    a.n = e.n;
+    a.s0 = e.s0;
+    a.batch = e.batch;
+    a.layout = e.layout;
+    a.do_scale = e.do_scale;
+    a.scale = (W) e.scale;
+    PassGeom g = pass_geometry(e.n, e.s0, Cfg::LOG_M, Cfg::LOG_C, Cfg::LOG_U, Cfg::CONTIG, e.batch, e.target_wgs);
+    a.ppw = g.ppw;
+    a.log_ul = g.log_ul;
+    a.log_uh = g.log_uh;
+    a.log_up = g.log_up;
+    EmuExec<Cfg> ex;
+    for (uint32_t by = 0; by < g.grid_y; by++)
+        for (uint32_t bx = 0; bx < g.grid_x; bx++) {
+            ex.bx = bx;
+            ex.by = by;
+            // poison the tile: a read of a word nobody wrote this launch shows up as garbage
+            memset(ex.tile.data(), 0xA5, ex.tile.size() * sizeof(W));
+            run_pass<Cfg>(ex, a);
+        }
+    return 0;
+}
+
+template <class F, bool INV>
+int dispatch(bool contig, int log_m, const Erased &e) {
+#define CASE_CONTIG(M)                                                                                \
+    case M:                                                                                           \
+        return run_cfg<PassCfg<F, M, 0, true, INV, (((M + 3) / 4) <= 2) || sizeof(typename F::W) == 4>>(e);
+#define CASE_COL(M) \
+    case M:         \
+        return run_cfg<PassCfg<F, M, LOG_COLS, false, INV, true>>(e);
+    if (contig) {
+        switch (log_m) {
+            CASE_CONTIG(1) CASE_CONTIG(2) CASE_CONTIG(3) CASE_CONTIG(4) CASE_CONTIG(5) CASE_CONTIG(6)
+            CASE_CONTIG(7) CASE_CONTIG(8) CASE_CONTIG(9) CASE_CONTIG(10) CASE_CONTIG(11) CASE_CONTIG(12)
+            default: return -1;
+        }
+    }
+    switch (log_m) {
+        CASE_COL(4) CASE_COL(5) CASE_COL(6) CASE_COL(7) CASE_COL(8)
+        default: return -1;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Forward (inverse = 0) or exact inverse (inverse = 1, scaled by N^-1 when scale != 0)
+// of `batch` polynomials, host buffers, table T in plain form (N words).
+// passes_override: 0 = planner's split; otherwise a list "first,col,col,.." packed
+// 4 bits each from the low nibble (used to exercise every tile shape).
+int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, const void *in, void *out,
+                  uint32_t batch, int inverse, int layout, int scale, uint32_t target_wgs,
+                  uint64_t passes_override) {
+    const size_t N = (size_t) 1 << logn;
+    std::vector<uint64_t> T(N), Ti;
+    for (size_t i = 0; i < N; i++)
+        T[i] = word_bytes == 4 ? ((const uint32_t *) T_plain)[i] : ((const uint64_t *) T_plain)[i];
+    if (inverse && !invert_table(T, p, Ti)) return -5;
+    const std::vector<uint64_t> &src = inverse ? Ti : T;
+    std::vector<uint32_t> t32;
+    std::vector<uint64_t> t64;
+    const void *tw;
+    if (word_bytes == 4) {
+        t32.resize(N);
+        for (size_t i = 0; i < N; i++) t32[i] = (uint32_t) to_table_form(src[i], p, 4);
+        tw = t32.data();
+    } else {
+        t64 = src;
+        tw = t64.data();
+    }
+    std::vector<PassDesc> passes;
+    if (passes_override == 0) {
+        passes = plan_passes(logn);
+    } else {
+        int s0 = 0;
+        bool first = true;
+        for (uint64_t v = passes_override; v; v >>= 4) {
+            int m = (int) (v & 15);
+            passes.push_back({first, s0, m});
+            s0 += m;
+            first = false;
+        }
+        if (s0 != logn) return -1;
+    }
+    Erased e;
+    memset(&e, 0, sizeof(e));
+    e.p = (uint32_t) p;
+    if (word_bytes == 4) {
+        e.pinv = mont_pinv((uint32_t) p);
+        e.r2 = mont_r2((uint32_t) p);
+    }
+    e.n = logn;
+    e.batch = batch;
+    e.layout = layout;
+    e.target_wgs = target_wgs;
+    e.tw = tw;
+    e.scale = to_table_form(powmod((p + 1) / 2, (uint64_t) logn, p), p, word_bytes);
+    const void *cur = in;
+    const size_t np = passes.size();
+    for (size_t k = 0; k < np; k++) {
+        const size_t i = inverse ? np - 1 - k : k;
+        e.in = cur;
+        e.out = out;
+        e.s0 = passes[i].s0;
+        e.do_scale = (inverse && scale && i == 0) ? 1 : 0;
+        int rc;
+        if (word_bytes == 8)
+            rc = inverse ? dispatch<FieldGL, true>(passes[i].contig, passes[i].log_m, e)
+                         : dispatch<FieldGL, false>(passes[i].contig, passes[i].log_m, e);
+        else
+            rc = inverse ? dispatch<FieldM32, true>(passes[i].contig, passes[i].log_m, e)
+                         : dispatch<FieldM32, false>(passes[i].contig, passes[i].log_m, e);
+        if (rc) return rc;
+        cur = out;
+    }
+    return 0;
+}
+
+// the planner's split, for tests: writes up to 8 (contig, s0, log_m) triples
+int emu_plan(int logn, int *out_triples) {
+    auto v = plan_passes(logn);
+    for (size_t i = 0; i < v.size() && i < 8; i++) {
+        out_triples[3 * i] = v[i].contig;
+        out_triples[3 * i + 1] = v[i].s0;
+        out_triples[3 * i + 2] = v[i].log_m;
+    }
+    return (int) v.size();
+}
+
+// field arithmetic spot checks
+uint64_t emu_gl_mul(uint64_t a, uint64_t b) { return FieldGL{}.mul(a, b); }
+uint64_t emu_gl_add(uint64_t a, uint64_t b) { return FieldGL{}.add(a, b); }
+uint64_t emu_gl_sub(uint64_t a, uint64_t b) { return FieldGL{}.sub(a, b); }
+uint32_t emu_m32_mul_plain(uint32_t a, uint32_t b, uint32_t p) {
+    FieldM32 f{p, mont_pinv(p), mont_r2(p)};
+    return f.mul_plain(a, b);
+}
+uint32_t emu_m32_add(uint32_t a, uint32_t b, uint32_t p) { return FieldM32{p, 0, 0}.add(a, b); }
+uint32_t emu_m32_sub(uint32_t a, uint32_t b, uint32_t p) { return FieldM32{p, 0, 0}.sub(a, b); }
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+"""The C-ABI library loads and exports every symbol include/ntt_hip.h declares.
+No compute calls: this runs on the CPU-only container."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def hiplib():
+    import __graft_entry__ as ge
+
+    if not os.path.exists(os.path.join(ROOT, "ntt_aie_amd", "libntt_hip.so")):
+        ge.build()
+    from ntt_aie_amd import _lib
+
+    return _lib
+
+
+def test_header_symbols_exported(hiplib):
+    hdr = open(os.path.join(ROOT, "include", "ntt_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ntt_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(hiplib.EXPORTS)
+    L = hiplib.lib()
+    for name in sorted(declared):
+        assert getattr(L, name) is not None, name
+
+
+def test_error_contract_without_compute(hiplib):
+    L = hiplib.lib()
+    assert L.ntt_version() >= 100
+    assert L.ntt_error_string(0) == b"ok"
+    for code in range(-8, 0):
+        assert L.ntt_error_string(code) not in (None, b"", b"unknown error")
+    h = C.c_void_p()
+    # argument errors are reported before any device is touched
+    assert L.ntt_plan_create(None, 8, 3329, 4, 0) == hiplib.NTT_E_ARG
+    assert L.ntt_plan_create(C.byref(h), 8, 3329, 3, 0) == hiplib.NTT_E_ARG
+    assert L.ntt_plan_create(C.byref(h), 0, 3329, 4, 0) == hiplib.NTT_E_LOGN
+    assert L.ntt_plan_create(C.byref(h), 29, 3329, 4, 0) == hiplib.NTT_E_LOGN
+    assert L.ntt_plan_create(C.byref(h), 8, 3330, 4, 0) == hiplib.NTT_E_PRIME
+    assert L.ntt_plan_create(C.byref(h), 8, 3329, 8, 0) == hiplib.NTT_E_PRIME
+    assert L.ntt_plan_create(C.byref(h), 8, (1 << 32) + 15, 4, 0) == hiplib.NTT_E_PRIME
+    assert L.ntt_forward(None, None, None, 1, 0, None) == hiplib.NTT_E_ARG
+    assert L.ntt_plan_destroy(None) == hiplib.NTT_E_ARG
+    if L.ntt_device_count() == 0:
+        assert L.ntt_plan_create(C.byref(h), 8, 3329, 4, 0) == hiplib.NTT_E_NODEVICE
+
+
+def test_product_has_no_oracle_dependency():
+    """The product package must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "ntt_aie_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".inc", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle_py" not in text and "ntt_oracle" not in text and "libntt_oracle" not in text, f

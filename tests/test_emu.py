@@ -1,0 +1,98 @@
+"""Host index model of the HIP pass kernels (same pass.h / field.h / plan.h,
+compiled with g++, all 256 lanes of a workgroup stepped phase by phase) against
+the oracle.  Checks the index rules, LDS exchange pattern, planner and modular
+arithmetic on the CPU-only container; the GPU tests then only have to confirm
+that the hardware agrees."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import emu_lib
+
+GOLD = 0xFFFFFFFF00000001
+FIELDS = [(8, GOLD, 7), (4, 3221225473, 5), (4, 3329, 3)]
+
+
+def _run(oracle, wb, logn, p, g, batch, inverse=0, layout=0, scale=1, tw=2048, ov=0, seed=0, inplace=False):
+    n = 1 << logn
+    dt = np.uint32 if wb == 4 else np.uint64
+    T = oracle.make_roots(n, p, g, wb)
+    rng = np.random.default_rng(seed)
+    a = (rng.integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p)).astype(dt)
+    if not inverse:
+        want = oracle.ntt(a, T, p, nthreads=4)
+        if layout:
+            want = oracle.block16(want)
+        src = a.copy()
+    else:
+        src = oracle.ntt(a, T, p, nthreads=4)
+        want = a.copy()
+        if layout:
+            src = oracle.block16(src)
+        if not scale:
+            want = ((want.astype(object) * n) % p).astype(dt)
+    out = src if inplace else np.zeros_like(a)
+    rc = emu_lib.lib().emu_transform(wb, logn, p, T.ctypes.data, src.ctypes.data, out.ctypes.data, batch,
+                                     inverse, layout, scale, tw, ov)
+    assert rc == 0
+    assert np.array_equal(out, want)
+
+
+@pytest.mark.parametrize("wb,p,g", FIELDS)
+def test_single_pass_sizes(oracle, wb, p, g):
+    for logn in range(1, 13):
+        for inv in (0, 1):
+            for batch in (1, 19):
+                _run(oracle, wb, logn, p, g, batch, inverse=inv, layout=int(logn >= 4 and batch == 19), seed=logn)
+
+
+@pytest.mark.parametrize("wb,p,g", FIELDS[:2])
+def test_multi_pass_planner_splits(oracle, wb, p, g):
+    for logn in (13, 16, 17):
+        for inv in (0, 1):
+            _run(oracle, wb, logn, p, g, 3, inverse=inv, layout=1, tw=8, seed=logn, inplace=True)
+
+
+@pytest.mark.parametrize("ov", [(8, 4), (8, 5), (7, 6), (8, 7), (8, 8), (12, 4), (5, 4), (4, 6), (5, 5, 8)])
+def test_every_tile_shape(oracle, ov):
+    logn = sum(ov)
+    for wb, p, g in FIELDS[:2]:
+        for inv in (0, 1):
+            _run(oracle, wb, logn, p, g, 2, inverse=inv, scale=inv, tw=4, ov=emu_lib.pack_passes(*ov), seed=7)
+
+
+def test_planner_covers_all_sizes():
+    tri = (C.c_int * 24)()
+    for logn in range(1, 29):
+        k = emu_lib.lib().emu_plan(logn, tri)
+        passes = [(tri[3 * i], tri[3 * i + 1], tri[3 * i + 2]) for i in range(k)]
+        assert passes[0][0] == 1 and passes[0][1] == 0 and 1 <= passes[0][2] <= 12
+        s0 = passes[0][2]
+        for contig, s, m in passes[1:]:
+            assert contig == 0 and s == s0 and 4 <= m <= 8
+            s0 += m
+        assert s0 == logn
+        assert k == (1 if logn <= 12 else 1 + -(-(logn - 12) // 8))  # fewest HBM passes
+
+
+def test_field_arithmetic_edges():
+    L = emu_lib.lib()
+    p = GOLD
+    edge = [0, 1, 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000, p - 1, p - 2, 0x8000000000000000,
+            0x7FFFFFFF80000001, 0xFFFFFFFE00000002]
+    rng = np.random.default_rng(0)
+    vals = edge + [int(x) % p for x in rng.integers(0, 2**63, size=64, dtype=np.uint64) * 2 + 1]
+    for a in vals:
+        for b in vals:
+            assert L.emu_gl_mul(a, b) == a * b % p
+            assert L.emu_gl_add(a, b) == (a + b) % p
+            assert L.emu_gl_sub(a, b) == (a - b) % p
+    for q in (3, 3329, 12289, 998244353, 2013265921, 3221225473, 4294967291):
+        ev = [0, 1, 2, q - 1, q - 2, q // 2, q // 2 + 1]
+        ev += [int(x) % q for x in rng.integers(0, 2**62, size=40)]
+        for a in ev:
+            for b in ev:
+                assert L.emu_m32_mul_plain(a, b, q) == a * b % q
+                assert L.emu_m32_add(a, b, q) == (a + b) % q
+                assert L.emu_m32_sub(a, b, q) == (a - b) % q

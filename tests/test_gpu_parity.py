@@ -1,0 +1,240 @@
+"""Parity of the HIP path against the oracle, through the C-ABI (libntt_hip.so),
+on a real MI355X.  Bit-exact: all arithmetic is integer."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+GOLD = 0xFFFFFFFF00000001
+FIELDS = [(8, GOLD, 7), (4, 3221225473, 5), (4, 998244353, 3), (4, 3329, 3)]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    import ntt_aie_amd as E
+
+    assert torch.cuda.is_available()
+    assert os.path.exists(E.LIB_PATH), "native library missing: the GPU tests must not pass without it"
+    torch.cuda.set_device(0)
+    return E
+
+
+def _rand(batch, n, p, dt, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p)).astype(dt)
+
+
+def _plan(eng, logn, p, wb, T):
+    pl = eng.NTTPlan(logn, p, wb, 0)
+    pl.set_twiddles(T)
+    return pl
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLDEN, "*_n*.npz"))))
+def test_golden_fixtures(eng, name):
+    """Committed vectors: literal reference code (p <= 46340) and big-int restatement."""
+    f = np.load(os.path.join(GOLDEN, name))
+    n, p = int(f["n"]), int(f["p"])
+    wb = 8 if p > 2**32 else 4
+    dt = np.uint32 if wb == 4 else np.uint64
+    T = f["table"].astype(dt)
+    pl = _plan(eng, n.bit_length() - 1, p, wb, T)
+    assert np.array_equal(pl.make_roots(int(f["g"])), T)  # table rule a2
+    for key in [k for k in f.files if k.startswith("in_")]:
+        tag = key[3:]
+        a = f[key].astype(dt)[None, :]
+        out = eng.to_host(pl.forward(eng.to_device(a, "cuda:0")))
+        assert np.array_equal(out[0], f["out_" + tag].astype(dt)), tag
+        if "out_%s_block16" % tag in f.files and n >= 16:
+            out = eng.to_host(pl.forward(eng.to_device(a, "cuda:0"), layout=eng.LAYOUT_AIE_BLOCK16))
+            assert np.array_equal(out[0], f["out_%s_block16" % tag].astype(dt))
+    if "partial_iota" in f.files:  # test_stage hook
+        a = f["in_iota"].astype(dt)[None, :]
+        for s, want in enumerate(f["partial_iota"]):
+            out = eng.to_host(pl.forward_stages(eng.to_device(a, "cuda:0"), s))
+            assert np.array_equal(out[0], want.astype(dt)), s
+
+
+@pytest.mark.parametrize("wb,p,g", FIELDS)
+@pytest.mark.parametrize("logn", list(range(1, 15)) + [16, 17])
+def test_forward_inverse_vs_oracle(eng, oracle, wb, p, g, logn):
+    n = 1 << logn
+    dt = np.uint32 if wb == 4 else np.uint64
+    T = oracle.make_roots(n, p, g, wb)
+    pl = _plan(eng, logn, p, wb, T)
+    for batch in (1, 5, 33):
+        if logn >= 16 and batch > 5:
+            continue
+        a = _rand(batch, n, p, dt, seed=logn * 100 + batch)
+        want = oracle.ntt(a, T, p, nthreads=8)
+        d = eng.to_device(a, "cuda:0")
+        f = pl.forward(d)
+        assert np.array_equal(eng.to_host(f), want), ("forward", batch)
+        assert np.array_equal(eng.to_host(d), a), "input buffer modified"
+        assert np.array_equal(eng.to_host(pl.inverse(f)), a), ("inverse", batch)
+        assert np.array_equal(eng.to_host(pl.inverse(eng.to_device(want, "cuda:0"))),
+                              oracle.intt(want, T, p, nthreads=8))
+        unscaled = eng.to_host(pl.inverse(f, scale=False))
+        assert np.array_equal(unscaled, ((a.astype(object) * n) % p).astype(dt))
+        # in place, both directions
+        g_ = eng.to_device(a, "cuda:0")
+        pl.forward(g_, g_)
+        assert np.array_equal(eng.to_host(g_), want)
+        pl.inverse(g_, g_)
+        assert np.array_equal(eng.to_host(g_), a)
+        if logn >= 4:
+            blk = pl.forward(d, layout=eng.LAYOUT_AIE_BLOCK16)
+            assert np.array_equal(eng.to_host(blk), oracle.block16(want))
+            assert np.array_equal(eng.to_host(pl.inverse(blk, layout=eng.LAYOUT_AIE_BLOCK16)), a)
+            h_ = eng.to_device(a, "cuda:0")
+            pl.forward(h_, h_, layout=eng.LAYOUT_AIE_BLOCK16)
+            assert np.array_equal(eng.to_host(h_), oracle.block16(want))
+        # the independent one-stage-per-launch path agrees too
+        assert np.array_equal(eng.to_host(pl.forward_stages(d, logn - 1)), want)
+
+
+def test_edge_values(eng, oracle):
+    """All-(p-1), all-zero, alternating extremes: every carry / borrow path."""
+    for wb, p, g in FIELDS:
+        dt = np.uint32 if wb == 4 else np.uint64
+        logn = 12
+        n = 1 << logn
+        T = oracle.make_roots(n, p, g, wb)
+        pl = _plan(eng, logn, p, wb, T)
+        rows = [np.full(n, p - 1), np.zeros(n), np.tile([0, p - 1], n // 2), np.tile([p - 1, 1, p - 2, 0], n // 4)]
+        a = np.stack([np.array(r, dtype=object) for r in rows]).astype(dt)
+        assert np.array_equal(eng.to_host(pl.forward(eng.to_device(a, "cuda:0"))), oracle.ntt(a, T, p))
+
+
+def test_arbitrary_table_and_noninvertible(eng, oracle):
+    """The kernel contract is the index rule T[h+i] only: any table of residues works;
+    a table with a zero entry has no inverse and says so."""
+    p, wb, logn = GOLD, 8, 10
+    n = 1 << logn
+    T = _rand(1, n, p, np.uint64, 99)[0]
+    pl = _plan(eng, logn, p, wb, T)
+    a = _rand(3, n, p, np.uint64, 5)
+    f = pl.forward(eng.to_device(a, "cuda:0"))
+    assert np.array_equal(eng.to_host(f), oracle.ntt(a, T, p))
+    assert np.array_equal(eng.to_host(pl.inverse(f)), a)
+    T[37] = 0
+    pl.set_twiddles(T)
+    assert not pl.has_inverse
+    assert np.array_equal(eng.to_host(pl.forward(eng.to_device(a, "cuda:0"))), oracle.ntt(a, T, p))
+    with pytest.raises(eng.NTTError) as ei:
+        pl.inverse(f)
+    assert ei.value.code == -5
+    T[37] = p  # out of range
+    with pytest.raises(eng.NTTError) as ei:
+        pl.set_twiddles(T)
+    assert ei.value.code == -7
+
+
+def test_error_paths(eng):
+    import torch
+
+    pl = eng.NTTPlan(8, 3329, 4, 0)
+    x = torch.zeros((2, 256), dtype=torch.int32, device="cuda:0")
+    with pytest.raises(eng.NTTError) as ei:
+        pl.forward(x)
+    assert ei.value.code == -4  # no table yet
+    pl3 = eng.NTTPlan(3, 3329, 4, 0)
+    pl3.set_twiddles(pl3.make_roots(3))
+    y = torch.zeros((2, 8), dtype=torch.int32, device="cuda:0")
+    with pytest.raises(eng.NTTError) as ei:
+        pl3.forward(y, layout=eng.LAYOUT_AIE_BLOCK16)
+    assert ei.value.code == -6
+    with pytest.raises(eng.NTTError):
+        eng.NTTPlan(8, 3330, 4, 0)
+    with pytest.raises(eng.NTTError):
+        eng.NTTPlan(8, 3329, 4, 99)
+    assert eng.to_host(pl3.forward(torch.zeros((0, 8), dtype=torch.int32, device="cuda:0"))).size == 0
+
+
+def test_pointwise_and_negacyclic_polymul(eng, oracle):
+    for wb, p, g in [(8, GOLD, 7), (4, 998244353, 3)]:
+        dt = np.uint32 if wb == 4 else np.uint64
+        for logn in (6, 8, 13):
+            n = 1 << logn
+            pl = eng.NTTPlan(logn, p, wb, 0)
+            T = pl.make_table(2, g)
+            assert np.array_equal(T.astype(np.uint64), oracle.make_table(2, n, p, g).astype(np.uint64))
+            pl.set_twiddles(T)
+            a, b = _rand(3, n, p, dt, 1), _rand(3, n, p, dt, 2)
+            da, db = eng.to_device(a, "cuda:0"), eng.to_device(b, "cuda:0")
+            pw = eng.to_host(pl.pointwise_mul(da, db, scale=12345))
+            assert np.array_equal(pw, oracle.pointwise(a, b, p, 12345))
+            c = eng.to_host(pl.polymul_negacyclic(da, db))
+            if logn <= 8:
+                want = np.stack([oracle.negacyclic_schoolbook(a[i], b[i], p) for i in range(3)]).astype(dt)
+            else:  # oracle pipeline
+                ninv = pow(n, p - 2, p)
+                A, B = oracle.intt(a, T, p), oracle.intt(b, T, p)
+                want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p)
+                assert ninv * n % p == 1
+            assert np.array_equal(c, want), (wb, logn)
+
+
+def test_full_size_properties(eng, oracle):
+    """BASELINE config 3 (N = 2^16, Goldilocks, batch 4096) at full size: sampled rows
+    against the oracle, round trip, and linearity (size-independent properties)."""
+    import torch
+
+    p, logn, batch = GOLD, 16, 4096
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, 8, 0)
+    T = pl.make_roots(7)
+    pl.set_twiddles(T)
+    gen = torch.Generator(device="cuda:0").manual_seed(1234)
+    x = torch.randint(0, 2**62, (batch, n), dtype=torch.int64, device="cuda:0", generator=gen)  # < p: canonical
+    y = torch.randint(0, 2**62, (batch, n), dtype=torch.int64, device="cuda:0", generator=gen)
+    X, Y = pl.forward(x), pl.forward(y)
+    rows = [0, 1, 777, 2048, 4095]
+    xs = eng.to_host(x[rows])
+    assert np.array_equal(eng.to_host(X[rows]), oracle.ntt(xs, T, p, nthreads=8))
+    assert torch.equal(pl.inverse(X), x)
+    s = x + y  # < 2^63 < p, still canonical
+    S = pl.forward(s)
+    Sh = eng.to_host(S[rows]).astype(object)
+    assert np.array_equal(Sh, (eng.to_host(X[rows]).astype(object) + eng.to_host(Y[rows]).astype(object)) % p)
+    # checksum of checksums: out[0] of every row is the plain coefficient sum
+    col0 = eng.to_host(X[:64, 0]).astype(object)
+    assert np.array_equal(col0, np.array([int(r.astype(object).sum()) % p for r in eng.to_host(x[:64])], dtype=object))
+
+
+def test_config2_u32_batch1024(eng, oracle):
+    """BASELINE config 2: N = 2^12, 32-bit prime, batch 1024 (single HBM pass)."""
+    for p, g in [(12289, 11), (3221225473, 5)]:
+        logn, batch = 12, 1024
+        n = 1 << logn
+        T = oracle.make_roots(n, p, g, 4)
+        pl = _plan(eng, logn, p, 4, T)
+        assert pl.hbm_passes == 1
+        a = _rand(batch, n, p, np.uint32, 3)
+        f = pl.forward(eng.to_device(a, "cuda:0"))
+        assert np.array_equal(eng.to_host(f), oracle.ntt(a, T, p, nthreads=8))
+        assert np.array_equal(eng.to_host(pl.inverse(f)), a)
+
+
+def test_config4_n20_polymul_sampled(eng, oracle):
+    """BASELINE config 4 shape (N = 2^20, two HBM passes) at a reduced batch."""
+    p, logn, batch = GOLD, 20, 4
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, 8, 0)
+    T = pl.make_table(2, 7)
+    pl.set_twiddles(T)
+    assert pl.hbm_passes == 2
+    a, b = _rand(batch, n, p, np.uint64, 11), _rand(batch, n, p, np.uint64, 12)
+    f = pl.forward(eng.to_device(a, "cuda:0"))
+    assert np.array_equal(eng.to_host(f[:2]), oracle.ntt(a[:2], T, p, nthreads=8))
+    assert np.array_equal(eng.to_host(pl.inverse(f)), a)
+    c = eng.to_host(pl.polymul_negacyclic(eng.to_device(a, "cuda:0"), eng.to_device(b, "cuda:0")))
+    A, B = oracle.intt(a[:1], T, p, nthreads=8), oracle.intt(b[:1], T, p, nthreads=8)
+    assert np.array_equal(c[:1], oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p))
