@@ -108,6 +108,15 @@ int64_t ntt_plan_info(ntt_plan_t plan, int what);
 int ntt_forward(ntt_plan_t plan, const void *d_in, void *d_out, size_t batch,
                 int out_layout, void *stream);
 
+/* Profiling twin of ntt_forward (the reference brackets one kernel iteration with
+ * trace events, src/aie_core.cc:129-131, src/aie2.py:168,316): identical launches
+ * with a hipEvent recorded on `stream` around every HBM pass; blocks until done.
+ * Writes the number of passes to *n_passes and their durations to ms_per_pass[]
+ * (capacity max_passes). */
+int ntt_forward_profile(ntt_plan_t plan, const void *d_in, void *d_out, size_t batch,
+                        int out_layout, void *stream, float *ms_per_pass, int max_passes,
+                        int *n_passes);
+
 /* Exact inverse of ntt_forward (no reference counterpart; BASELINE configs 3-4):
  * stages logN-1..0, (u, v) -> (u + v/T, u - v/T), then * N^-1 when scale != 0.
  * d_in is in `in_layout` (what ntt_forward produced), d_out natural order. */
@@ -120,8 +129,8 @@ int ntt_pointwise_mul(ntt_plan_t plan, const void *d_a, const void *d_b, void *d
                       size_t batch, uint64_t scale, void *stream);
 
 /* Negacyclic product c = a*b mod (x^N + 1, p) with a kind-2 table loaded:
- * inverse-network (unscaled) on a and b -> pointwise * N^-1... folded constant
- * -> forward network.  d_a and d_b are overwritten (used as scratch);
+ * unscaled inverse network on a and b -> pointwise product * N^-1 -> forward
+ * network.  d_a and d_b are overwritten (used as scratch);
  * d_out may alias d_a. */
 int ntt_polymul_negacyclic(ntt_plan_t plan, void *d_a, void *d_b, void *d_out,
                            size_t batch, void *stream);

@@ -262,6 +262,39 @@ int ntt_forward(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int 
     return run_forward(pl, d_in, d_out, batch, out_layout, (hipStream_t) stream);
 }
 
+int ntt_forward_profile(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int out_layout,
+                        void *stream, float *ms_per_pass, int max_passes, int *n_passes) {
+    int rc = check_io(pl, d_in, d_out, batch);
+    if (rc) return rc;
+    if (!ms_per_pass || !n_passes || max_passes < (int) pl->passes.size()) return NTT_E_ARG;
+    *n_passes = (int) pl->passes.size();
+    if (!pl->has_table) return NTT_E_NOTABLE;
+    if (batch == 0) return NTT_OK;
+    DeviceGuard g(pl->device);
+    if (g.err != hipSuccess) return (int) g.err;
+    hipStream_t s = (hipStream_t) stream;
+    const size_t np = pl->passes.size();
+    std::vector<hipEvent_t> ev(np + 1);
+    for (auto &e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return (int) hipGetLastError();
+    const void *src = d_in;
+    hipError_t e = hipEventRecord(ev[0], s);
+    for (size_t i = 0; i < np && e == hipSuccess; i++) {
+        const PassDesc &pd = pl->passes[i];
+        ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
+        a.tw = pl->d_tw_fwd;
+        a.layout = out_layout;
+        e = pl->word_bytes == 8 ? ntt::launch_gl_fwd(pd.contig, pd.log_m, a, s)
+                                : ntt::launch_m32_fwd(pd.contig, pd.log_m, a, s);
+        if (e == hipSuccess) e = hipEventRecord(ev[i + 1], s);
+        src = d_out;
+    }
+    if (e == hipSuccess) e = hipEventSynchronize(ev[np]);
+    for (size_t i = 0; i < np && e == hipSuccess; i++) e = hipEventElapsedTime(&ms_per_pass[i], ev[i], ev[i + 1]);
+    for (auto &x : ev) (void) hipEventDestroy(x);
+    return (int) e;
+}
+
 int ntt_inverse(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int in_layout, int scale,
                 void *stream) {
     int rc = check_io(pl, d_in, d_out, batch);

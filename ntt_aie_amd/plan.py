@@ -123,6 +123,17 @@ class NTTPlan:
                                      self._stream(stream)), "ntt_forward")
         return out
 
+    def forward_profile(self, inp: torch.Tensor, out: torch.Tensor | None = None,
+                        layout: int = LAYOUT_NATURAL, stream=None) -> list[float]:
+        """forward() with a hipEvent pair around every HBM pass; returns ms per pass (blocking)."""
+        out = torch.empty_like(inp) if out is None else out
+        b = self._batch(inp, out)
+        ms = (C.c_float * 8)()
+        k = C.c_int(0)
+        check(_lib.lib().ntt_forward_profile(self._h, inp.data_ptr(), out.data_ptr(), b, layout,
+                                             self._stream(stream), ms, 8, C.byref(k)), "ntt_forward_profile")
+        return [float(ms[i]) for i in range(k.value)]
+
     def inverse(self, inp: torch.Tensor, out: torch.Tensor | None = None, layout: int = LAYOUT_NATURAL,
                 scale: bool = True, stream=None) -> torch.Tensor:
         out = torch.empty_like(inp) if out is None else out
