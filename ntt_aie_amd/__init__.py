@@ -14,7 +14,6 @@ def version() -> int:
 
 
 def __getattr__(name):
-    # torch is imported lazily so the ABI checks (ctypes only) run without it
     if name in ("NTTPlan", "GOLDILOCKS", "to_device", "to_host"):
         from . import plan
         return getattr(plan, name)

@@ -50,6 +50,14 @@ def lib() -> C.CDLL:
             raise ImportError(
                 "libntt_hip.so is not built (%s). Build it with `make -C ntt_aie_amd/csrc` or "
                 "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  Import
+        # torch first so that this library's NEEDED libamdhip64.so.7 resolves (by soname) to
+        # the copy torch already mapped; loading ours first would pull in /opt/rocm's copy and
+        # the second runtime to initialise would see no device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
         L.ntt_version.restype = C.c_int

@@ -67,8 +67,11 @@ ntt::ErasedArgs base_args(const ntt_plan *pl, const PassDesc &pd, const void *in
     return a;
 }
 
+// batch == 0 is a valid no-op whatever the pointers are (an empty torch tensor has a null data_ptr)
 int check_io(const ntt_plan *pl, const void *a, const void *b, size_t batch) {
-    if (!pl || !a || !b) return NTT_E_ARG;
+    if (!pl) return NTT_E_ARG;
+    if (batch == 0) return NTT_OK;
+    if (!a || !b) return NTT_E_ARG;
     if (((uintptr_t) a | (uintptr_t) b) & 15u) return NTT_E_ARG;  // 16-byte vector accesses
     if (batch > 0x7FFFFFFFull) return NTT_E_ARG;
     return NTT_OK;
@@ -313,7 +316,7 @@ int ntt_pointwise_mul(ntt_plan_t pl, const void *d_a, const void *d_b, void *d_o
                       uint64_t scale, void *stream) {
     int rc = check_io(pl, d_a, d_b, batch);
     if (rc) return rc;
-    if (!d_out || ((uintptr_t) d_out & 15u)) return NTT_E_ARG;
+    if (batch && (!d_out || ((uintptr_t) d_out & 15u))) return NTT_E_ARG;
     if (scale >= pl->p) return NTT_E_RANGE;
     if (batch == 0) return NTT_OK;
     DeviceGuard g(pl->device);
@@ -329,7 +332,7 @@ int ntt_pointwise_mul(ntt_plan_t pl, const void *d_a, const void *d_b, void *d_o
 int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, size_t batch, void *stream) {
     int rc = check_io(pl, d_a, d_b, batch);
     if (rc) return rc;
-    if (!d_out || ((uintptr_t) d_out & 15u)) return NTT_E_ARG;
+    if (batch && (!d_out || ((uintptr_t) d_out & 15u))) return NTT_E_ARG;
     if (!pl->has_table) return NTT_E_NOTABLE;
     if (!pl->has_inv) return NTT_E_NOTINVERTIBLE;
     if (batch == 0) return NTT_OK;

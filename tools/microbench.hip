@@ -85,30 +85,41 @@ __global__ void bench(uint64_t *out, unsigned long long *cycles, int iters) {
 
 template <int K>
 void run(uint64_t *d_out, unsigned long long *d_cyc) {
-    const int iters = 200, insts = 64;
-    for (int waves_per_simd : {1, 2, 4}) {
-        const int threads = 64 * 4 * waves_per_simd;  // one block per CU, all four SIMDs
-        const int blocks = 256;
+    const int iters = 2000, insts = 64;
+    for (int waves_per_simd : {1, 2, 4, 8}) {
+        // 1024-thread blocks hold 4 waves per SIMD; 8 per SIMD = two such blocks per CU
+        const int threads = waves_per_simd >= 4 ? 1024 : 64 * 4 * waves_per_simd;
+        const int blocks = 256 * (waves_per_simd >= 4 ? waves_per_simd / 4 : 1);
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
         hipLaunchKernelGGL(bench<K>, dim3(blocks), dim3(threads), 0, 0, d_out, d_cyc, iters);
+        hipEventRecord(e0, 0);
         hipLaunchKernelGGL(bench<K>, dim3(blocks), dim3(threads), 0, 0, d_out, d_cyc, iters);
+        hipEventRecord(e1, 0);
         hipDeviceSynchronize();
-        unsigned long long h[256];
-        hipMemcpy(h, d_cyc, sizeof(h), hipMemcpyDeviceToHost);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        unsigned long long h[512];
+        hipMemcpy(h, d_cyc, sizeof(unsigned long long) * blocks, hipMemcpyDeviceToHost);
         double avg = 0;
         for (int i = 0; i < blocks; i++) avg += (double) h[i];
         avg /= blocks;
         // one wave issued iters*insts instructions; waves_per_simd waves share a SIMD
         double cyc_per_inst_per_simd = avg / ((double) iters * insts * waves_per_simd);
-        printf("%-34s waves/SIMD=%d  wave-time=%9.0f cyc  -> %.2f cyc per wave-instruction per SIMD\n", NAMES[K],
-               waves_per_simd, avg, cyc_per_inst_per_simd);
+        // wall-clock view: every SIMD of the chip retired iters*insts*waves_per_simd wave-instructions
+        double ns_per_inst_per_simd = (double) ms * 1e6 / ((double) iters * insts * waves_per_simd);
+        printf("%-34s waves/SIMD=%d  wave-time=%9.0f ticks  -> %.2f ticks (%.3f ns wall) per wave-instruction per SIMD"
+               "  [kernel %.1f us => %.0f MHz tick]\n", NAMES[K], waves_per_simd, avg, cyc_per_inst_per_simd,
+               ns_per_inst_per_simd, ms * 1e3, avg / (ms * 1e3));
     }
 }
 
 int main() {
     uint64_t *d_out;
     unsigned long long *d_cyc;
-    hipMalloc(&d_out, 256 * 1024 * 8);
-    hipMalloc(&d_cyc, 256 * 8);
+    hipMalloc(&d_out, 512 * 1024 * 8);
+    hipMalloc(&d_cyc, 512 * 8);
     hipDeviceProp_t pr;
     hipGetDeviceProperties(&pr, 0);
     printf("device %s, %d CUs, clock %d kHz (s_memtime ticks at the shader clock)\n", pr.gcnArchName,
