@@ -8,8 +8,9 @@
 //   FieldM32 : 4-byte words, any odd p < 2^32.  Twiddles are kept in Montgomery
 //              form (T * 2^32 mod p) so one product costs v_mad_u64_u32 +
 //              v_mul_lo_u32 + v_mul_hi_u32 and returns the canonical x*T mod p.
-//   FieldGL  : 8-byte words, p = 2^64 - 2^32 + 1.  64x64->128 product from four
-//              v_mad_u64_u32, then the 2^64 = 2^32 - 1, 2^96 = -1 reduction.
+//   FieldGL  : 8-byte words, p = 2^64 - 2^32 + 1.  Twiddles in Montgomery form
+//              (T * 2^64 mod p); 64x64->128 product from four v_mad_u64_u32, then the
+//              shift/add Montgomery reduction special to this prime.
 // All inputs must be canonical; all outputs are canonical.
 #pragma once
 #include <stdint.h>
@@ -70,29 +71,33 @@ struct FieldGL {
         uint64_t d = a - b;
         return (a < b) ? d - EPS : d;  // + p == - EPS (mod 2^64)
     }
-    NTT_HD W mul(W a, W b) const {
-        uint32_t a0 = (uint32_t) a, a1 = (uint32_t) (a >> 32);
-        uint32_t b0 = (uint32_t) b, b1 = (uint32_t) (b >> 32);
-        uint64_t p00 = (uint64_t) a0 * b0;
-        uint64_t p01 = (uint64_t) a0 * b1 + (p00 >> 32);
-        uint64_t p10 = (uint64_t) a1 * b0 + (uint32_t) p01;
-        uint64_t hi = (uint64_t) a1 * b1 + (p01 >> 32) + (p10 >> 32);
-        uint64_t lo = (p10 << 32) | (uint32_t) p00;
-        return reduce128(lo, hi);
+    // x canonical, tw = T * 2^64 mod p (Montgomery form)  ->  x*T mod p, canonical.
+    // With p = 2^64 - 2^32 + 1, p^-1 = 1 + 2^32 (mod 2^64), so the Montgomery quotient
+    // m = lo * p^-1 and (m*p) >> 64 are shifts and adds of the low product half:
+    //   a = lo + (lo << 32)            (carry e)
+    //   b = a - (a >> 32) - e          = (m*p) >> 64, always < p
+    //   r = hi - b  (mod p)            one conditional  - (2^32 - 1)
+    // (the shift/add form of Goldilocks Montgomery reduction used by plonky2).
+    NTT_HD W mul(W x, W tw) const {
+        const uint32_t x0 = (uint32_t) x, x1 = (uint32_t) (x >> 32);
+        const uint32_t t0 = (uint32_t) tw, t1 = (uint32_t) (tw >> 32);
+        const uint64_t ll = (uint64_t) x0 * t0;
+        const uint64_t m1 = (uint64_t) x0 * t1 + (ll >> 32);   // fits: (2^32-1)^2 + 2^32-1 < 2^64
+        const uint64_t q = (uint64_t) x1 * t0;
+        const uint64_t m2 = q + m1;                            // may wrap
+        const uint64_t cm = m2 < q ? 1u : 0u;
+        const uint64_t hi = (uint64_t) x1 * t1 + ((cm << 32) | (m2 >> 32));
+        const uint32_t p0 = (uint32_t) ll, p1 = (uint32_t) m2; // lo = p1:p0
+        const uint32_t a1 = p1 + p0;
+        const uint32_t e = a1 < p0 ? 1u : 0u;
+        const uint64_t a = ((uint64_t) a1 << 32) | p0;
+        const uint64_t b = a - a1 - e;
+        const uint64_t r = hi - b;
+        return (hi < b) ? r - EPS : r;
     }
-    // lo + 2^64*hi mod p, canonical
-    static NTT_HD W reduce128(uint64_t lo, uint64_t hi) {
-        uint32_t hh = (uint32_t) (hi >> 32), hl = (uint32_t) hi;
-        uint64_t t0 = lo - hh;                    // 2^96 = -1
-        if (lo < hh) t0 -= EPS;
-        uint64_t t1 = ((uint64_t) hl << 32) - hl; // hl * (2^32 - 1), 2^64 = 2^32 - 1
-        uint64_t t2 = t0 + t1;
-        if (t2 < t1) t2 += EPS;                   // cannot wrap twice: t1 <= 2^64 - 2^33 + 1
-        uint64_t t3 = t2 + EPS;
-        return (t3 < t2) ? t3 : t2;               // t2 >= p -> t2 - p
-    }
-    NTT_HD W mul_plain(W x, W y) const { return mul(x, y); }
-    NTT_HD W to_table_form(W t) const { return t; }
+    static constexpr uint64_t R2 = 0xFFFFFFFE00000001ULL;  // 2^128 mod p
+    NTT_HD W mul_plain(W x, W y) const { return mul(mul(x, y), R2); }
+    NTT_HD W to_table_form(W t) const { return mul(t, R2); }
 };
 
 }  // namespace ntt

@@ -214,8 +214,10 @@ int ntt_plan_set_twiddles(ntt_plan_t pl, const void *host_T) {
             ((uint32_t *) buf_i.data())[i] = (uint32_t) to_table_form(Ti[i], p, 4);
         }
     } else {
-        memcpy(buf_f.data(), T.data(), N * 8);
-        memcpy(buf_i.data(), Ti.data(), N * 8);
+        for (size_t i = 0; i < N; i++) {
+            ((uint64_t *) buf_f.data())[i] = to_table_form(T[i], p, 8);
+            ((uint64_t *) buf_i.data())[i] = to_table_form(Ti[i], p, 8);
+        }
     }
     DeviceGuard g(pl->device);
     if (g.err != hipSuccess) return (int) g.err;

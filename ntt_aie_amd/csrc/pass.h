@@ -36,6 +36,7 @@
 #include <type_traits>
 
 #include "field.h"
+#include "gl_asm.h"
 
 namespace ntt {
 
@@ -158,6 +159,13 @@ NTT_HD size_t uniform_word(const Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
            (pg << (a.log_up + a.n));
 }
 
+template <class Cfg, int r>
+constexpr bool tw_uniform() {
+    // column pass with one unit per workgroup, outermost window: the twiddle index has no
+    // lane-dependent part, so the table entries live in SGPRs
+    return !Cfg::CONTIG && Cfg::LOG_U == 0 && (Cfg::win(r) + Cfg::LOG_E >= Cfg::LOG_M);
+}
+
 // ---- phases -------------------------------------------------------------------
 template <class Cfg, int r>
 NTT_HD void load_twiddles(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
@@ -172,7 +180,17 @@ NTT_HD void load_twiddles(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
         const uint32_t base = (1u << (a.n - s - 1)) + (c.hi << (Cfg::LOG_M - m - 1)) +
                               (q_hi << (Cfg::LOG_E - t - 1));
 #pragma unroll
-        for (int k = 0; k < cnt; ++k) c.tw[r][off + k] = a.tw[base + k];
+        for (int k = 0; k < cnt; ++k) {
+            typename Cfg::W v = a.tw[base + k];
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (tw_uniform<Cfg, r>() && sizeof(typename Cfg::W) == 8) {
+                const uint32_t v0 = __builtin_amdgcn_readfirstlane((uint32_t) v);
+                const uint32_t v1 = __builtin_amdgcn_readfirstlane((uint32_t) ((uint64_t) v >> 32));
+                v = (typename Cfg::W) (((uint64_t) v1 << 32) | v0);
+            }
+#endif
+            c.tw[r][off + k] = v;
+        }
     });
 }
 
@@ -308,6 +326,9 @@ NTT_HD void phase_lds_write(Ctx<Cfg> &c, typename Cfg::W *lds) {
 // The butterflies of round r (src/aie_core.cc:104-125 ntt_stage_parallel8;
 // src/test.cpp:46-50).  Forward: (x, y) -> (x + y, (x - y) * T), stages ascending.
 // Inverse: (u, v) -> (u + v/T, u - v/T), stages descending.
+// On the device the Goldilocks butterflies run as hand-scheduled instruction streams,
+// two independent butterflies per statement (gl_asm.h); everything else, and the host
+// index model, uses the portable Field arithmetic -- same words either way.
 template <class Cfg, int r>
 NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
     using W = typename Cfg::W;
@@ -319,6 +340,25 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
         constexpr int m = Cfg::INV ? (hi - 1 - decltype(kk)::value) : (lo + decltype(kk)::value);
         constexpr int t = m - b0;
         constexpr int off = Cfg::E - (Cfg::E >> t);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (std::is_same<typename Cfg::F, FieldGL>::value && Cfg::E >= 4) {
+            // butterfly k of this stage: low element index with bit t cleared
+            static_for<0, Cfg::E / 4>([&](auto pp) {
+                constexpr int k0 = 2 * decltype(pp)::value, k1 = k0 + 1;
+                constexpr int eA = ((k0 >> t) << (t + 1)) | (k0 & ((1 << t) - 1));
+                constexpr int eB = ((k1 >> t) << (t + 1)) | (k1 & ((1 << t) - 1));
+                const W TA = c.tw[r][off + (eA >> (t + 1))], TB = c.tw[r][off + (eB >> (t + 1))];
+                if constexpr (tw_uniform<Cfg, r>()) {
+                    if constexpr (!Cfg::INV) gl_fwd2_s(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
+                    else gl_inv2_s(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
+                } else {
+                    if constexpr (!Cfg::INV) gl_fwd2_v(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
+                    else gl_inv2_v(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
+                }
+            });
+            return;
+        }
+#endif
 #pragma unroll
         for (int e = 0; e < Cfg::E; ++e) {
             if (e & (1 << t)) continue;
@@ -340,6 +380,15 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
 template <class Cfg>
 NTT_HD void phase_scale(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
     if (!a.do_scale) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (std::is_same<typename Cfg::F, FieldGL>::value && Cfg::E >= 2) {
+        static_for<0, Cfg::E / 2>([&](auto pp) {
+            constexpr int e = 2 * decltype(pp)::value;
+            gl_mul2_s(c.x[e], a.scale, c.x[e + 1], a.scale);
+        });
+        return;
+    }
+#endif
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) c.x[e] = a.field.mul(c.x[e], a.scale);
 }

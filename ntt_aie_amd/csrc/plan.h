@@ -74,7 +74,7 @@ inline uint32_t mont_r2(uint32_t p) { return (uint32_t) ((((u128) 1) << 64) % p)
 
 // value -> the form the kernels keep twiddles in
 inline uint64_t to_table_form(uint64_t t, uint64_t p, int word_bytes) {
-    return word_bytes == 4 ? (uint64_t) ((((u128) t) << 32) % p) : t;
+    return (uint64_t) ((((u128) t) << (word_bytes == 4 ? 32 : 64)) % p);  // Montgomery form, R = 2^32 / 2^64
 }
 
 // Tinv[i] = T[i]^-1 for i >= 1 by batch inversion; false when some T[i] == 0

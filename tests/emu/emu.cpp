@@ -138,7 +138,8 @@ int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, con
         for (size_t i = 0; i < N; i++) t32[i] = (uint32_t) to_table_form(src[i], p, 4);
         tw = t32.data();
     } else {
-        t64 = src;
+        t64.resize(N);
+        for (size_t i = 0; i < N; i++) t64[i] = to_table_form(src[i], p, 8);
         tw = t64.data();
     }
     std::vector<PassDesc> passes;
@@ -201,7 +202,7 @@ int emu_plan(int logn, int *out_triples) {
 }
 
 // field arithmetic spot checks
-uint64_t emu_gl_mul(uint64_t a, uint64_t b) { return FieldGL{}.mul(a, b); }
+uint64_t emu_gl_mul(uint64_t a, uint64_t b) { return FieldGL{}.mul_plain(a, b); }
 uint64_t emu_gl_add(uint64_t a, uint64_t b) { return FieldGL{}.add(a, b); }
 uint64_t emu_gl_sub(uint64_t a, uint64_t b) { return FieldGL{}.sub(a, b); }
 uint32_t emu_m32_mul_plain(uint32_t a, uint32_t b, uint32_t p) {

@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Generate ntt_aie_amd/csrc/gl_asm.h: hand-scheduled gfx950 instruction streams for the
+Goldilocks butterflies (two independent butterflies interleaved per asm statement).
+
+Why asm: on gfx950 a VALU instruction that reads an SGPR/VCC written by a VALU instruction
+needs two other instructions in between (the compiler pads with s_nop), and hipcc turns the
+64-bit compare/select idiom into v_cmp_lt_u64 + 2x v_cndmask instead of carry chains.  One
+butterfly is 24 VALU instructions when written with v_add_co/v_addc_co/v_subb_co chains:
+
+  sub   d = x - y (mod p)                    4 VALU + 1 SALU
+  mul   r = d * T  (T in Montgomery form)    4 v_mad_u64_u32 + 10 VALU + 1 SALU
+  add   s = x + y (mod p)                    6 VALU + 1 SALU
+
+The two butterflies' instructions are merged by a list scheduler that keeps every
+SGPR producer->consumer pair at least 3 slots apart, so no s_nop is needed.
+
+Register use inside a statement: data words and 32-bit temporaries are compiler-allocated
+operands; the 64-bit products need aligned VGPR pairs whose halves are used separately, which
+inline-asm operands cannot express, so they live in fixed VGPRs v[108:127] (clobbers), and the
+carries in fixed SGPR pairs s[84:99] + vcc.
+"""
+import sys
+
+SGPR_DIST = 3  # producer slot + 3 <= consumer slot  (two instructions in between)
+
+
+class Ins:
+    def __init__(self, text, reads=(), writes=(), salu=False):
+        self.text, self.reads, self.writes, self.salu = text, set(reads), set(writes), salu
+
+
+def is_sgpr(r):
+    return r.startswith("s") or r == "vcc"
+
+
+def butterfly(kind, b):
+    """Instruction list of butterfly `b` (0/1).  kind: 'fwd' | 'inv' | 'mul'.
+    Operand names: x0 x1 y0 y1 t0 t1 (compiler operands, suffixed by b), temporaries
+    d0 d1 z0 z1 u0 u1 (operands), fixed pairs L M A B H, SGPR pairs sa sb se sf."""
+    vb = 108 + 10 * b
+    L, M, A, B, H = [(f"v{vb + 2 * i}", f"v{vb + 2 * i + 1}") for i in range(5)]
+    sb_ = 84 + 8 * b
+    sa, sbb, se, sf = [f"s[{sb_ + 2 * i}:{sb_ + 2 * i + 1}]" for i in range(4)]
+
+    def P(pair):
+        lo = int(pair[0][1:])
+        return f"v[{lo}:{lo + 1}]"
+
+    def o(name):  # compiler-allocated operand
+        return f"%[{name}{b}]"
+
+    x0, x1, y0, y1, t0, t1 = o("x0_"), o("x1_"), o("y0_"), o("y1_"), o("t0_"), o("t1_")
+    d0, d1, z0, z1, u0, u1 = o("d0_"), o("d1_"), o("z0_"), o("z1_"), o("u0_"), o("u1_")
+    ins = []
+
+    def sub(dst0, dst1, a0, a1, b0, b1, tmp0, tmp1, final0, final1):
+        # (a - b) mod p: wrapped difference, then - borrow*(2^32-1)
+        ins.append(Ins(f"v_sub_co_u32 {tmp0}, {sa}, {a0}, {b0}", [a0, b0], [tmp0, sa]))
+        ins.append(Ins(f"v_subb_co_u32 {tmp1}, {sa}, {a1}, {b1}, {sa}", [a1, b1, sa], [tmp1, sa]))
+        ins.append(Ins(f"v_addc_co_u32 {final0}, {sbb}, {tmp0}, 0, {sa}", [tmp0, sa], [final0, sbb]))
+        ins.append(Ins(f"s_andn2_b64 {sa}, {sa}, {sbb}", [sa, sbb], [sa], salu=True))
+        ins.append(Ins(f"v_subbrev_co_u32 {final1}, {sa}, 0, {tmp1}, {sa}", [tmp1, sa], [final1, sa]))
+
+    def add(a0, a1, b0, b1, out0, out1):
+        # (a + b) mod p: sum, sum + (2^32-1), pick the second when either carried
+        ins.append(Ins(f"v_add_co_u32 {z0}, {se}, {a0}, {b0}", [a0, b0], [z0, se]))
+        ins.append(Ins(f"v_addc_co_u32 {z1}, {se}, {a1}, {b1}, {se}", [a1, b1, se], [z1, se]))
+        ins.append(Ins(f"v_add_co_u32 {u0}, {sf}, -1, {z0}", [z0], [u0, sf]))
+        ins.append(Ins(f"v_addc_co_u32 {u1}, {sf}, 0, {z1}, {sf}", [z1, sf], [u1, sf]))
+        ins.append(Ins(f"s_or_b64 {se}, {se}, {sf}", [se, sf], [se], salu=True))
+        ins.append(Ins(f"v_cndmask_b32 {out0}, {z0}, {u0}, {se}", [z0, u0, se], [out0]))
+        ins.append(Ins(f"v_cndmask_b32 {out1}, {z1}, {u1}, {se}", [z1, u1, se], [out1]))
+
+    def mul(m0, m1, r0, r1):
+        # (m1:m0) * (t1:t0) * 2^-64 mod p, canonical; m may be any 64-bit value
+        ins.append(Ins(f"v_mad_u64_u32 {P(L)}, vcc, {m0}, {t0}, 0", [m0, t0], [L[0], L[1], "vcc"]))
+        ins.append(Ins(f"v_mov_b32 {A[0]}, {L[1]}", [L[1]], [A[0]]))
+        ins.append(Ins(f"v_mov_b32 {A[1]}, 0", [], [A[1]]))
+        ins.append(Ins(f"v_mad_u64_u32 {P(M)}, vcc, {m0}, {t1}, {P(A)}", [m0, t1, A[0], A[1]], [M[0], M[1], "vcc"]))
+        ins.append(Ins(f"v_mad_u64_u32 {P(M)}, {sa}, {m1}, {t0}, {P(M)}", [m1, t0, M[0], M[1]], [M[0], M[1], sa]))
+        ins.append(Ins(f"v_mov_b32 {B[0]}, {M[1]}", [M[1]], [B[0]]))
+        ins.append(Ins(f"v_cndmask_b32 {B[1]}, 0, 1, {sa}", [sa], [B[1]]))
+        ins.append(Ins(f"v_mad_u64_u32 {P(H)}, vcc, {m1}, {t1}, {P(B)}", [m1, t1, B[0], B[1]], [H[0], H[1], "vcc"]))
+        # Montgomery: a1 = P1 + P0 (carry e); b = (a1:P0) - a1 - e; r = H - b (mod p)
+        ins.append(Ins(f"v_add_co_u32 {A[0]}, {sa}, {M[0]}, {L[0]}", [M[0], L[0]], [A[0], sa]))
+        ins.append(Ins(f"v_subb_co_u32 {B[0]}, {sbb}, {L[0]}, {A[0]}, {sa}", [L[0], A[0], sa], [B[0], sbb]))
+        ins.append(Ins(f"v_subbrev_co_u32 {B[1]}, {sbb}, 0, {A[0]}, {sbb}", [A[0], sbb], [B[1], sbb]))
+        ins.append(Ins(f"v_sub_co_u32 {L[0]}, {sa}, {H[0]}, {B[0]}", [H[0], B[0]], [L[0], sa]))
+        ins.append(Ins(f"v_subb_co_u32 {L[1]}, {sa}, {H[1]}, {B[1]}, {sa}", [H[1], B[1], sa], [L[1], sa]))
+        ins.append(Ins(f"v_addc_co_u32 {r0}, {sbb}, {L[0]}, 0, {sa}", [L[0], sa], [r0, sbb]))
+        ins.append(Ins(f"s_andn2_b64 {sa}, {sa}, {sbb}", [sa, sbb], [sa], salu=True))
+        ins.append(Ins(f"v_subbrev_co_u32 {r1}, {sa}, 0, {L[1]}, {sa}", [L[1], sa], [r1, sa]))
+
+    if kind == "fwd":    # x' = x + y ; y' = (x - y) * T
+        sub(d0, d1, x0, x1, y0, y1, d0, d1, d0, d1)
+        add(x0, x1, y0, y1, x0, x1)
+        mul(d0, d1, y0, y1)
+    elif kind == "inv":  # w = y * T ; x' = x + w ; y' = x - w
+        mul(y0, y1, d0, d1)
+        sub(y0, y1, x0, x1, d0, d1, y0, y1, y0, y1)
+        add(x0, x1, d0, d1, x0, x1)
+    elif kind == "mul":  # x' = x * T
+        mul(x0, x1, x0, x1)
+    return ins
+
+
+def schedule(lists):
+    """Merge instruction lists (each in program order) keeping dependencies; SGPR RAW pairs
+    SGPR_DIST slots apart.  Returns lines (s_nop inserted only if unavoidable)."""
+    nodes = []
+    for li, lst in enumerate(lists):
+        for k, ins in enumerate(lst):
+            nodes.append((li, k, ins))
+    n = len(nodes)
+    preds = [[] for _ in range(n)]  # (pred index, min distance)
+    for j in range(n):
+        lj, kj, ij = nodes[j]
+        for i in range(n):
+            li, ki, ii = nodes[i]
+            if li != lj or ki >= kj:
+                continue
+            dist = 0
+            raw = ii.writes & ij.reads
+            if raw:
+                dist = max(dist, SGPR_DIST if any(is_sgpr(r) for r in raw) else 1)
+            if (ii.reads & ij.writes) or (ii.writes & ij.writes):
+                dist = max(dist, 1)
+            if dist:
+                preds[j].append((i, dist))
+    # priority = longest path to the end
+    succs = [[] for _ in range(n)]
+    for j in range(n):
+        for i, d in preds[j]:
+            succs[i].append((j, d))
+    prio = [0] * n
+    for i in reversed(range(n)):
+        prio[i] = max([d + prio[j] for j, d in succs[i]], default=0)
+    slot = [None] * n
+    out, t, done = [], 0, 0
+    while done < n:
+        best = None
+        for j in range(n):
+            if slot[j] is not None:
+                continue
+            if all(slot[i] is not None and slot[i] + d <= t for i, d in preds[j]):
+                if best is None or prio[j] > prio[best]:
+                    best = j
+        if best is None:
+            out.append("s_nop 0")
+        else:
+            slot[best] = t
+            out.append(nodes[best][2].text)
+            done += 1
+        t += 1
+    return out
+
+
+def emit(kind, nb, tw_constraint):
+    lists = [butterfly(kind, b) for b in range(nb)]
+    lines = schedule(lists)
+    nops = sum(1 for l in lines if l.startswith("s_nop"))
+    name = f"gl_{kind}{nb}_{'s' if tw_constraint == 's' else 'v'}"
+    args = []
+    for b in range(nb):
+        if kind == "mul":
+            args += [f"uint64_t &x{b}", f"uint64_t t{b}"]
+        else:
+            args += [f"uint64_t &x{b}", f"uint64_t &y{b}", f"uint64_t t{b}"]
+    src = [f"// {kind} x{nb}: {len(lines)} instructions, {nops} s_nop",
+           f"__device__ __forceinline__ void {name}({', '.join(args)}) {{"]
+    for b in range(nb):
+        src.append(f"    uint32_t x0_{b} = (uint32_t) x{b}, x1_{b} = (uint32_t) (x{b} >> 32);")
+        if kind != "mul":
+            src.append(f"    uint32_t y0_{b} = (uint32_t) y{b}, y1_{b} = (uint32_t) (y{b} >> 32);")
+        src.append(f"    const uint32_t t0_{b} = (uint32_t) t{b}, t1_{b} = (uint32_t) (t{b} >> 32);")
+        if kind != "mul":
+            src.append(f"    uint32_t d0_{b}, d1_{b}, z0_{b}, z1_{b}, u0_{b}, u1_{b};")
+    src.append("    asm volatile(")
+    for l in lines:
+        src.append(f'        "{l}\\n\\t"')
+    outs, ins_ = [], []
+    for b in range(nb):
+        outs += [f'[x0_{b}] "+v"(x0_{b})', f'[x1_{b}] "+v"(x1_{b})']
+        if kind != "mul":
+            outs += [f'[y0_{b}] "+v"(y0_{b})', f'[y1_{b}] "+v"(y1_{b})']
+            outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("d0_", "d1_", "z0_", "z1_", "u0_", "u1_")]
+        ins_ += [f'[t0_{b}] "{tw_constraint}"(t0_{b})', f'[t1_{b}] "{tw_constraint}"(t1_{b})']
+    clob = ['"vcc"'] + [f'"v{r}"' for r in range(108, 108 + 10 * nb)] + [f'"s{r}"' for r in range(84, 84 + 8 * nb)]
+    src.append("        : " + ", ".join(outs))
+    src.append("        : " + ", ".join(ins_))
+    src.append("        : " + ", ".join(clob) + ");")
+    for b in range(nb):
+        src.append(f"    x{b} = ((uint64_t) x1_{b} << 32) | x0_{b};")
+        if kind != "mul":
+            src.append(f"    y{b} = ((uint64_t) y1_{b} << 32) | y0_{b};")
+    src.append("}")
+    return "\n".join(src), len(lines), nops
+
+
+def main():
+    out = ["// gl_asm.h -- GENERATED by tools/gen_gl_asm.py; do not edit.",
+           "// Hand-scheduled gfx950 Goldilocks butterflies (two interleaved per statement); the",
+           "// portable definition of the same arithmetic is FieldGL in field.h, and the GPU parity",
+           "// tests hold the two bit-for-bit equal.  Replaces src/aie_core.cc:41-125.",
+           "#pragma once", "#include <stdint.h>", "#if defined(__HIP_DEVICE_COMPILE__)", "namespace ntt {", ""]
+    for kind in ("fwd", "inv", "mul"):
+        for tw in ("v", "s"):
+            txt, n, nops = emit(kind, 2, tw)
+            out.append(txt)
+            out.append("")
+            print(f"{kind} x2 tw={tw}: {n} instructions, {nops} nops", file=sys.stderr)
+    out += ["}  // namespace ntt", "#endif"]
+    open(sys.argv[1] if len(sys.argv) > 1 else "ntt_aie_amd/csrc/gl_asm.h", "w").write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()
