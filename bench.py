@@ -42,6 +42,7 @@ def cpu_baseline(logn, p, table, budget_s=12.0):
 
     n = 1 << logn
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, int(os.environ.get("NTT_BENCH_CPU_THREADS", "16")))  # the box's CPU share for one GPU
     rng = np.random.default_rng(1)
     probe = rng.integers(0, 2**63, size=(2, n), dtype=np.uint64)
     t0 = time.perf_counter()
@@ -141,14 +142,26 @@ def main():
         t_kernels = float(per_pass.sum()) * 1e-3
         achieved = alg_bytes / t_kernels / 1e9
         dom = int(per_pass.argmax())
+        # HBM bytes per launch from the PMC counters (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
+        # same command, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_pmc_traffic.json
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        names = ["pass_contig_8", "pass_col_8"]
+        if os.path.exists(pmc) and logn == 16 and batch == 4096:
+            k = json.load(open(pmc))["kernels"]
+            traffic = sum(k[nm]["hbm_bytes_per_launch"] for nm in names)
+            traffic_src = "profiles/r01_pmc_traffic.json"
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "definition": "algorithmic bytes of one forward transform (2*N*8 B) x batch / summed duration of its "
+                          "%d pass kernels (hipEvents on the launch stream); traffic = PMC HBM bytes of the "
+                          "same launches" % plan.hbm_passes,
             "algorithmic_bytes_per_transform": 2 * n * 8, "passes": plan.hbm_passes,
-            "pass_ms": [float(v) for v in per_pass],
-            "dominant_pass": dom,
-            # each pass reads and writes the whole batch once: its own physical stream rate
-            "pass_physical_GBs": [alg_bytes / (float(v) * 1e-3) / 1e9 for v in per_pass],
+            "pass_ms": [float(v) for v in per_pass], "dominant_pass": dom,
+            # each pass kernel reads and writes every coefficient once: its own stream rate
+            "pass_stream_GBs": [alg_bytes / (float(v) * 1e-3) / 1e9 for v in per_pass],
+            "pass_stream_frac": [alg_bytes / (float(v) * 1e-3) / 1e9 / HBM_PEAK_GBS for v in per_pass],
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(logn, p, eng.table)
