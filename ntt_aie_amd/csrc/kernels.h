@@ -23,6 +23,7 @@ struct ErasedArgs {
     int do_scale;
     uint64_t scale;  // table form
     uint32_t target_wgs;
+    int dbg;  // timing experiments (NTT_DEBUG_FLAGS), 0 in production
 };
 
 // Each returns hipSuccess / a hipError_t; hipErrorInvalidValue for an

@@ -45,6 +45,7 @@ struct ntt_plan {
     uint64_t scale_tf;     // N^-1 in table form
     uint64_t ninv_plain;   // N^-1 plain
     uint32_t target_wgs;
+    int dbg;
     std::vector<PassDesc> passes;
 };
 
@@ -64,6 +65,7 @@ ntt::ErasedArgs base_args(const ntt_plan *pl, const PassDesc &pd, const void *in
     a.s0 = pd.s0;
     a.batch = (uint32_t) batch;
     a.target_wgs = pl->target_wgs;
+    a.dbg = pl->dbg;
     return a;
 }
 
@@ -170,6 +172,8 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
         long v = atol(e);
         if (v > 0 && v < (1 << 24)) pl->target_wgs = (uint32_t) v;
     }
+    pl->dbg = 0;
+    if (const char *e = getenv("NTT_DEBUG_FLAGS")) pl->dbg = atoi(e);
     pl->passes = plan_passes(logn);
     DeviceGuard g(device);
     if (g.err != hipSuccess) {

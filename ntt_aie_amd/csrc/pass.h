@@ -57,7 +57,7 @@ NTT_HD void static_for(Fn &&f) {
     }
 }
 
-template <class F_, int LOG_M_, int LOG_C_, bool CONTIG_, bool INV_, bool PRELOAD_ = true>
+template <class F_, int LOG_M_, int LOG_C_, bool CONTIG_, bool INV_, int PRELOAD_MASK_ = 0xF, int LOG_E_ = 4>
 struct PassCfg {
     using F = F_;
     using W = typename F::W;
@@ -65,9 +65,12 @@ struct PassCfg {
     static constexpr int LOG_C = LOG_C_;  // log2 columns (lo values) per tile; 0 when CONTIG
     static constexpr bool CONTIG = CONTIG_;
     static constexpr bool INV = INV_;
-    static constexpr bool PRELOAD = PRELOAD_;
-    static constexpr int LOG_E = LOG_M < 4 ? LOG_M : 4;
-    static constexpr int E = 1 << LOG_E;  // words per thread
+    // bit r set: round r's twiddles are loaded once per workgroup and stay in registers across the
+    // batch loop; clear: reloaded (L2-resident table) at the start of the round, every iteration
+    static constexpr int PRELOAD_MASK = PRELOAD_MASK_;
+    static constexpr bool preload(int r) { return (PRELOAD_MASK >> r) & 1; }
+    static constexpr int LOG_E = LOG_M < LOG_E_ ? LOG_M : LOG_E_;
+    static constexpr int E = 1 << LOG_E;  // words per thread (radix of a register round)
     static constexpr int M = 1 << LOG_M;
     static constexpr int C = 1 << LOG_C;
     static constexpr int LOG_Q = LOG_M - LOG_E;  // threads along mid
@@ -88,9 +91,36 @@ struct PassCfg {
     // bits (high window); otherwise the tile is staged linearly through LDS.
     static constexpr bool DIRECT_LOAD = !CONTIG || R == 1 || INV;
     static constexpr bool DIRECT_STORE = !CONTIG || R == 1 || !INV;
+    // A CONTIG unit of <= 1024 words is owned by <= 64 consecutive threads, i.e. by ONE wave, and the
+    // linear staging is wave-segmented too: every LDS word is written and read by the same wave, so
+    // the exchanges need no workgroup barrier (LDS operations of a wave execute in order) and the
+    // four waves of a workgroup run fully decoupled.
+    static constexpr bool WAVE_LOCAL = CONTIG && (LOG_M - LOG_E) <= 6;
 
     static NTT_HD uint32_t lds_index(uint32_t lin) { return lin + ((lin >> LOG_E) * VW); }
 };
+
+// Which rounds of a CONTIG pass keep their twiddles in registers across the batch loop.
+// 8-byte words: 30 VGPRs per round; with two rounds resident the kernel drops to 3 waves/SIMD,
+// so only the first executed... (policy tuned on the device)
+#ifndef NTT_CONTIG_GL_MASK2
+#define NTT_CONTIG_GL_MASK2 0x3
+#endif
+// Radix of the register rounds of a CONTIG pass.  Goldilocks passes of 7-8 stages that are not
+// the last pass of the plan run radix-8 rounds (3+3+2 stages): 16 data + 34 twiddle registers
+// instead of 32 + 60, so ~5 waves per SIMD hide the HBM latency that 3 waves could not.
+constexpr int contig_log_e(int log_m, int word_bytes, bool last_pass) {
+    return (word_bytes == 8 && !last_pass && (log_m == 7 || log_m == 8)) ? 3 : 4;
+}
+
+constexpr int contig_preload_mask(int log_m, int word_bytes, int log_e = 4) {
+    if (log_e < 4) return 0xF;
+    const int rounds = (log_m + 3) / 4;
+    if (word_bytes == 4) return 0xF;
+    if (rounds <= 1) return 0xF;
+    if (rounds == 2) return NTT_CONTIG_GL_MASK2;
+    return 0x0;
+}
 
 template <class Cfg>
 struct PassArgs {
@@ -108,6 +138,7 @@ struct PassArgs {
     int log_up;
     int layout;    // transform-domain layout; honoured by the pass holding the top stage
     int do_scale;  // inverse: multiply by `scale` (N^-1, table form) after the last round
+    int dbg;       // timing experiments only (bit 0: every iteration re-reads polynomial group 0)
     W scale;
 };
 
@@ -154,7 +185,7 @@ NTT_HD size_t uniform_word(const Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     const int log_ltb = Cfg::CONTIG ? 0 : a.s0 - Cfg::LOG_C - a.log_ul;
     const uint32_t ltb = Cfg::CONTIG ? 0u : (c.bx & ((1u << log_ltb) - 1u));
     const uint32_t hb = Cfg::CONTIG ? c.bx : (c.bx >> log_ltb);
-    const size_t pg = (size_t) c.by * (uint32_t) a.ppw + (uint32_t) it;
+    const size_t pg = (a.dbg & 1) ? 0 : (size_t) c.by * (uint32_t) a.ppw + (uint32_t) it;
     return ((size_t) hb << (a.log_uh + a.s0 + Cfg::LOG_M)) + ((size_t) ltb << (a.log_ul + Cfg::LOG_C)) +
            (pg << (a.log_up + a.n));
 }
@@ -221,15 +252,17 @@ NTT_HD void phase_init(Ctx<Cfg> &c, const PassArgs<Cfg> &a, uint32_t tid, uint32
         const uint32_t mid0 = (q_hi << (b0 + Cfg::LOG_E)) | q_lo;
         c.lds_base[r] = Cfg::lds_index((((u << Cfg::LOG_M) | mid0) << Cfg::LOG_C) | col);
     });
-    if constexpr (Cfg::PRELOAD) {
-        static_for<0, Cfg::R>([&](auto rr) { load_twiddles<Cfg, decltype(rr)::value>(c, a); });
-    }
+    static_for<0, Cfg::R>([&](auto rr) {
+        if constexpr (Cfg::preload(decltype(rr)::value)) load_twiddles<Cfg, decltype(rr)::value>(c, a);
+    });
 }
 
 template <class Cfg>
 NTT_HD void phase_begin_iter(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
+    // run_pass() stops at the first polynomial group past the batch, so a lane can only be
+    // inactive when several polynomials share one workgroup (log_up > 0: ragged tail)
     const uint32_t poly = ((c.by * (uint32_t) a.ppw + (uint32_t) it) << a.log_up) | c.up;
-    c.active = poly < a.batch;
+    c.active = Cfg::LOG_U == 0 ? true : poly < a.batch;
 }
 
 // element number as seen by the transform-domain layout: in the pass that holds the
@@ -245,15 +278,55 @@ NTT_HD uint32_t elem_eff(const PassArgs<Cfg> &a, int e, bool want) {
     }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Buffer (SRD) addressing for the direct global accesses: wave-uniform descriptor base
+// (workgroup tile origin of this iteration) + SGPR element offset + one 32-bit lane offset,
+// so a load or store is ONE instruction with no per-element VALU address arithmetic.
+template <class W>
+__device__ __forceinline__ W buf_load(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    if constexpr (sizeof(W) == 8) {
+        using v2 = __attribute__((ext_vector_type(2))) unsigned int;
+        const v2 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+        return ((uint64_t) d.y << 32) | d.x;
+    } else {
+        return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+    }
+}
+template <class W>
+__device__ __forceinline__ void buf_store(W v, __amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+    if constexpr (sizeof(W) == 8) {
+        using v2 = __attribute__((ext_vector_type(2))) unsigned int;
+        v2 d;
+        d.x = (uint32_t) v;
+        d.y = (uint32_t) ((uint64_t) v >> 32);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff, soff, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(v, rs, voff, soff, 0);
+    }
+}
+#endif
+
 template <class Cfg, int r>
 NTT_HD void phase_load_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     using W = typename Cfg::W;
     const W *ubase = a.in + uniform_word<Cfg>(c, a, it);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // element offsets stay below 2^32 bytes: (E-1) << (n - LOG_E) words at most
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) ubase, 0, -1, 0x00020000);
+    const uint32_t voff = c.lane_ld * (uint32_t) sizeof(W);
+#pragma unroll
+    for (int e = 0; e < Cfg::E; ++e) {
+        const uint32_t so = (elem_eff<Cfg>(a, e, Cfg::INV) << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W);
+        c.x[e] = (W) 0;
+        if (c.active) c.x[e] = buf_load<W>(rs, voff, so);
+    }
+#else
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
         const size_t eo = (size_t) elem_eff<Cfg>(a, e, Cfg::INV) << (Cfg::win(r) + a.s0);
         c.x[e] = c.active ? (ubase + eo)[c.lane_ld] : (W) 0;
     }
+#endif
 }
 
 template <class Cfg, int r>
@@ -261,11 +334,21 @@ NTT_HD void phase_store_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     using W = typename Cfg::W;
     W *ubase = a.out + uniform_word<Cfg>(c, a, it);
     if (!c.active) return;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) ubase, 0, -1, 0x00020000);
+    const uint32_t voff = c.lane_st * (uint32_t) sizeof(W);
+#pragma unroll
+    for (int e = 0; e < Cfg::E; ++e) {
+        const uint32_t so = (elem_eff<Cfg>(a, e, !Cfg::INV) << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W);
+        buf_store<W>(c.x[e], rs, voff, so);
+    }
+#else
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
         const size_t eo = (size_t) elem_eff<Cfg>(a, e, !Cfg::INV) << (Cfg::win(r) + a.s0);
         (ubase + eo)[c.lane_st] = c.x[e];
     }
+#endif
 }
 
 template <class W, int V>
@@ -285,11 +368,13 @@ NTT_HD void phase_linear(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *l
     using Ch = Chunk<W, V>;
     const size_t tile0 = uniform_word<Cfg>(c, a, it);
     const uint32_t pg0 = (c.by * (uint32_t) a.ppw + (uint32_t) it) << a.log_up;
-    const uint32_t lbase = Cfg::lds_index(c.tid * V);
+    // wave w stages its own contiguous 64*E words: 1 KiB per wave-instruction, lanes along chunks
+    const uint32_t wbase = (c.tid >> 6) << (6 + Cfg::LOG_E);
+    const uint32_t lbase = Cfg::lds_index(wbase + (c.tid & 63u) * V);
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
-        constexpr uint32_t STEP = NT * V;  // multiple of E: pad term is linear in i
-        const uint32_t lin = (uint32_t) i * STEP + c.tid * V;
+        constexpr uint32_t STEP = 64 * V;  // multiple of E: pad term is linear in i
+        const uint32_t lin = wbase + (uint32_t) i * STEP + (c.tid & 63u) * V;
         // unit of this chunk -> its polynomial (ragged batch tail)
         const uint32_t u_p = (lin >> Cfg::LOG_M) >> a.log_uh;
         const bool active = (pg0 | u_p) < a.batch;
@@ -334,7 +419,7 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
     using W = typename Cfg::W;
     constexpr int b0 = Cfg::win(r);
     constexpr int lo = Cfg::stage_lo(r), hi = Cfg::stage_hi(r);
-    if constexpr (!Cfg::PRELOAD) load_twiddles<Cfg, r>(c, a);
+    if constexpr (!Cfg::preload(r)) load_twiddles<Cfg, r>(c, a);
     const typename Cfg::F &f = a.field;
     static_for<0, hi - lo>([&](auto kk) {
         constexpr int m = Cfg::INV ? (hi - 1 - decltype(kk)::value) : (lo + decltype(kk)::value);
@@ -351,6 +436,9 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
                 if constexpr (tw_uniform<Cfg, r>()) {
                     if constexpr (!Cfg::INV) gl_fwd2_s(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
                     else gl_inv2_s(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
+                } else if constexpr (Cfg::LOG_E < 4) {  // light kernels: asm scratch lives lower (v[76:95])
+                    if constexpr (!Cfg::INV) gl_fwd2_v_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
+                    else gl_inv2_v_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
                 } else {
                     if constexpr (!Cfg::INV) gl_fwd2_v(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
                     else gl_inv2_v(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
@@ -405,12 +493,13 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     constexpr bool ANY_LDS = R > 1 || !Cfg::DIRECT_LOAD || !Cfg::DIRECT_STORE;
     ex.init(a);
     for (int it = 0; it < a.ppw; ++it) {
+        if ((((uint64_t) ex.block_y() * (uint32_t) a.ppw + (uint32_t) it) << a.log_up) >= a.batch) break;  // uniform
         ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, it); });
         if constexpr (Cfg::DIRECT_LOAD) {
             ex.each([&](C &c) { phase_load_direct<Cfg, FIRST>(c, a, it); });
         } else {
             ex.each([&](C &c) { phase_linear<Cfg, true>(c, a, ex.lds(), it); });
-            ex.sync();
+            ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
             ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, ex.lds()); });
         }
         static_for<0, R>([&](auto kk) {
@@ -420,7 +509,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             if constexpr (k < R - 1) {
                 constexpr int rn = Cfg::INV ? r - 1 : r + 1;
                 ex.each([&](C &c) { phase_lds_write<Cfg, r>(c, ex.lds()); });
-                ex.sync();
+                ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
                 ex.each([&](C &c) { phase_lds_read<Cfg, rn>(c, ex.lds()); });
             }
         });
@@ -429,11 +518,11 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.each([&](C &c) { phase_store_direct<Cfg, LAST>(c, a, it); });
         } else {
             ex.each([&](C &c) { phase_lds_write<Cfg, LAST>(c, ex.lds()); });
-            ex.sync();
+            ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
             ex.each([&](C &c) { phase_linear<Cfg, false>(c, a, ex.lds(), it); });
         }
         if constexpr (ANY_LDS) {
-            if (it + 1 < a.ppw) ex.sync();  // next iteration rewrites the tile
+            ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});  // next iteration rewrites the tile
         }
     }
 }

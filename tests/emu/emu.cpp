@@ -30,11 +30,17 @@ struct EmuExec {
     void init(const PassArgs<Cfg> &a) {
         for (int t = 0; t < NT; t++) phase_init<Cfg>(ctx[t], a, (uint32_t) t, bx, by);
     }
+    // only_wave >= 0: step just that wave's 64 lanes (used to prove WAVE_LOCAL passes never read
+    // another wave's LDS words: the four waves are then run one after the other, start to finish)
+    int only_wave = -1;
     template <class Fn>
     void each(Fn &&f) {
-        for (int t = 0; t < NT; t++) f(ctx[t]);
+        const int lo = only_wave < 0 ? 0 : 64 * only_wave, hi = only_wave < 0 ? NT : lo + 64;
+        for (int t = lo; t < hi; t++) f(ctx[t]);
     }
-    void sync() {}
+    template <class B>
+    void sync(B) {}
+    uint32_t block_y() const { return by; }
     typename Cfg::W *lds() { return tile.data(); }
 };
 
@@ -75,6 +81,7 @@ int run_cfg(const Erased &e) {
     a.layout = e.layout;
     a.do_scale = e.do_scale;
     a.scale = (W) e.scale;
+    a.dbg = 0;
     PassGeom g = pass_geometry(e.n, e.s0, Cfg::LOG_M, Cfg::LOG_C, Cfg::LOG_U, Cfg::CONTIG, e.batch, e.target_wgs);
     a.ppw = g.ppw;
     a.log_ul = g.log_ul;
@@ -87,7 +94,15 @@ int run_cfg(const Erased &e) {
             ex.by = by;
             // poison the tile: a read of a word nobody wrote this launch shows up as garbage
             memset(ex.tile.data(), 0xA5, ex.tile.size() * sizeof(W));
-            run_pass<Cfg>(ex, a);
+            if constexpr (Cfg::WAVE_LOCAL) {
+                for (int w = 0; w < NT / 64; w++) {
+                    ex.only_wave = w;
+                    run_pass<Cfg>(ex, a);
+                    memset(ex.tile.data(), 0x5A, ex.tile.size() * sizeof(W));  // nothing may survive
+                }
+            } else {
+                run_pass<Cfg>(ex, a);
+            }
         }
     return 0;
 }
@@ -96,11 +111,15 @@ template <class F, bool INV>
 int dispatch(bool contig, int log_m, const Erased &e) {
 #define CASE_CONTIG(M)                                                                                \
     case M:                                                                                           \
-        return run_cfg<PassCfg<F, M, 0, true, INV, (((M + 3) / 4) <= 2) || sizeof(typename F::W) == 4>>(e);
+        return run_cfg<PassCfg<F, M, 0, true, INV, contig_preload_mask(M, sizeof(typename F::W))>>(e);
 #define CASE_COL(M) \
     case M:         \
-        return run_cfg<PassCfg<F, M, LOG_COLS, false, INV, true>>(e);
+        return run_cfg<PassCfg<F, M, LOG_COLS, false, INV, 0xF>>(e);
     if (contig) {
+        if (contig_log_e(log_m, sizeof(typename F::W), e.s0 + log_m == e.n) == 3) {
+            if (log_m == 7) return run_cfg<PassCfg<F, 7, 0, true, INV, 0xF, 3>>(e);
+            return run_cfg<PassCfg<F, 8, 0, true, INV, 0xF, 3>>(e);
+        }
         switch (log_m) {
             CASE_CONTIG(1) CASE_CONTIG(2) CASE_CONTIG(3) CASE_CONTIG(4) CASE_CONTIG(5) CASE_CONTIG(6)
             CASE_CONTIG(7) CASE_CONTIG(8) CASE_CONTIG(9) CASE_CONTIG(10) CASE_CONTIG(11) CASE_CONTIG(12)

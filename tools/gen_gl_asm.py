@@ -33,11 +33,11 @@ def is_sgpr(r):
     return r.startswith("s") or r == "vcc"
 
 
-def butterfly(kind, b):
+def butterfly(kind, b, vbase=108):
     """Instruction list of butterfly `b` (0/1).  kind: 'fwd' | 'inv' | 'mul'.
     Operand names: x0 x1 y0 y1 t0 t1 (compiler operands, suffixed by b), temporaries
     d0 d1 z0 z1 u0 u1 (operands), fixed pairs L M A B H, SGPR pairs sa sb se sf."""
-    vb = 108 + 10 * b
+    vb = vbase + 10 * b
     L, M, A, B, H = [(f"v{vb + 2 * i}", f"v{vb + 2 * i + 1}") for i in range(5)]
     sb_ = 84 + 8 * b
     sa, sbb, se, sf = [f"s[{sb_ + 2 * i}:{sb_ + 2 * i + 1}]" for i in range(4)]
@@ -155,11 +155,11 @@ def schedule(lists):
     return out
 
 
-def emit(kind, nb, tw_constraint):
-    lists = [butterfly(kind, b) for b in range(nb)]
+def emit(kind, nb, tw_constraint, vbase=108, suffix=""):
+    lists = [butterfly(kind, b, vbase) for b in range(nb)]
     lines = schedule(lists)
     nops = sum(1 for l in lines if l.startswith("s_nop"))
-    name = f"gl_{kind}{nb}_{'s' if tw_constraint == 's' else 'v'}"
+    name = f"gl_{kind}{nb}_{'s' if tw_constraint == 's' else 'v'}{suffix}"
     args = []
     for b in range(nb):
         if kind == "mul":
@@ -185,7 +185,7 @@ def emit(kind, nb, tw_constraint):
             outs += [f'[y0_{b}] "+v"(y0_{b})', f'[y1_{b}] "+v"(y1_{b})']
             outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("d0_", "d1_", "z0_", "z1_", "u0_", "u1_")]
         ins_ += [f'[t0_{b}] "{tw_constraint}"(t0_{b})', f'[t1_{b}] "{tw_constraint}"(t1_{b})']
-    clob = ['"vcc"'] + [f'"v{r}"' for r in range(108, 108 + 10 * nb)] + [f'"s{r}"' for r in range(84, 84 + 8 * nb)]
+    clob = ['"vcc"'] + [f'"v{r}"' for r in range(vbase, vbase + 10 * nb)] + [f'"s{r}"' for r in range(84, 84 + 8 * nb)]
     src.append("        : " + ", ".join(outs))
     src.append("        : " + ", ".join(ins_))
     src.append("        : " + ", ".join(clob) + ");")
@@ -209,6 +209,10 @@ def main():
             out.append(txt)
             out.append("")
             print(f"{kind} x2 tw={tw}: {n} instructions, {nops} nops", file=sys.stderr)
+        if kind != "mul":
+            txt, n, nops = emit(kind, 2, "v", vbase=76, suffix="_lo")  # for the radix-8 (light) kernels
+            out.append(txt)
+            out.append("")
     out += ["}  // namespace ntt", "#endif"]
     open(sys.argv[1] if len(sys.argv) > 1 else "ntt_aie_amd/csrc/gl_asm.h", "w").write("\n".join(out) + "\n")
 
