@@ -81,7 +81,7 @@ struct PassCfg {
     static constexpr int VW = 16 / (int) sizeof(W);        // words per 16-byte chunk
     static constexpr int TILE_WORDS = NT * E;
     // one 16-byte pad per E words keeps 16-byte alignment and skews the lanes
-    static constexpr int LDS_WORDS = TILE_WORDS + (TILE_WORDS >> LOG_E) * VW;
+    static constexpr int LDS_WORDS = TILE_WORDS + (TILE_WORDS >> LOG_E) * VW;  // (2 * TILE_WORDS when DMA)
 
     static constexpr int win(int r) { return r * LOG_E > LOG_M - LOG_E ? LOG_M - LOG_E : r * LOG_E; }
     static constexpr int stage_lo(int r) { return r * LOG_E; }
@@ -96,8 +96,13 @@ struct PassCfg {
     // the exchanges need no workgroup barrier (LDS operations of a wave execute in order) and the
     // four waves of a workgroup run fully decoupled.
     static constexpr bool WAVE_LOCAL = CONTIG && (LOG_M - LOG_E) <= 6;
+    // Forward CONTIG radix-8 pass on 8-byte words: the tile of the NEXT polynomial is fetched
+    // straight into a second LDS buffer by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no VALU)
+    // while the current one is transformed, so no wave ever waits on HBM in steady state.  The
+    // DMA writes 1 KiB per wave-instruction linearly, hence these tiles are not padded.
+    static constexpr bool DMA = WAVE_LOCAL && !INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8;
 
-    static NTT_HD uint32_t lds_index(uint32_t lin) { return lin + ((lin >> LOG_E) * VW); }
+    static NTT_HD uint32_t lds_index(uint32_t lin) { return DMA ? lin : lin + ((lin >> LOG_E) * VW); }
 };
 
 // Which rounds of a CONTIG pass keep their twiddles in registers across the batch loop.
@@ -166,7 +171,7 @@ struct Ctx {
 template <class Cfg>
 constexpr uint32_t lds_elem_off(int r, int e) {
     const uint32_t lin = (uint32_t) e << (Cfg::win(r) + Cfg::LOG_C);
-    return lin + ((lin >> Cfg::LOG_E) * Cfg::VW);
+    return Cfg::DMA ? lin : lin + ((lin >> Cfg::LOG_E) * Cfg::VW);
 }
 
 // lane part of the word index for the round whose window starts at b0
@@ -394,6 +399,52 @@ NTT_HD void phase_linear(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *l
     }
 }
 
+// ---- LDS-DMA prefetch (Cfg::DMA) ---------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+// one wave-instruction: lane l copies 16 bytes from its own global address to
+// LDS[lds_byte (wave-uniform) + 16*l].  M0 carries the LDS base and is restored (hipcc reserves it).
+__device__ __forceinline__ void glds16(const void *gptr, uint32_t lds_byte) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gptr), "s"(lds_byte)
+                 : "memory");
+}
+#endif
+
+// issue the copy of the tile of iteration `it` into LDS buffer (it & 1); wave-segmented like phase_linear
+template <class Cfg>
+NTT_HD void phase_dma_issue(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *lds, int it) {
+    using W = typename Cfg::W;
+    constexpr int V = Cfg::VW;
+    constexpr int ITER = Cfg::E / V;
+    const size_t tile0 = uniform_word<Cfg>(c, a, it);
+    const uint32_t wbase = (c.tid >> 6) << (6 + Cfg::LOG_E);
+    const uint32_t buf = (uint32_t) (it & 1) * Cfg::TILE_WORDS;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) W *) lds;
+    const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(lds0 + (buf + wbase) * (uint32_t) sizeof(W));
+    const W *g = a.in + tile0 + wbase + (c.tid & 63u) * V;
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) glds16(g + i * 64 * V, wave_lds + (uint32_t) i * 64 * V * (uint32_t) sizeof(W));
+#else
+    for (int i = 0; i < ITER; ++i) {
+        const uint32_t lin = wbase + (uint32_t) i * 64 * V + (c.tid & 63u) * V;
+        for (int k = 0; k < V; ++k) lds[buf + lin + k] = a.in[tile0 + lin + k];
+    }
+#endif
+}
+
+// wait until this wave's DMA of the current tile has landed.  VMEM operations retire in order:
+// the only younger ones are the E stores of the previous iteration, which may stay in flight.
+template <class Cfg, bool FIRST_ITER>
+NTT_HD void phase_dma_wait() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (FIRST_ITER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::E) : "memory");
+#endif
+}
+
 template <class Cfg, int r>
 NTT_HD void phase_lds_read(Ctx<Cfg> &c, const typename Cfg::W *lds) {
     const typename Cfg::W *p = lds + c.lds_base[r];
@@ -492,15 +543,27 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     constexpr int LAST = Cfg::INV ? 0 : R - 1;
     constexpr bool ANY_LDS = R > 1 || !Cfg::DIRECT_LOAD || !Cfg::DIRECT_STORE;
     ex.init(a);
+    auto group_valid = [&](int it) {  // uniform: does polynomial group `it` of this workgroup exist
+        return it < a.ppw && (((uint64_t) ex.block_y() * (uint32_t) a.ppw + (uint32_t) it) << a.log_up) < a.batch;
+    };
+    if constexpr (Cfg::DMA) {
+        if (group_valid(0)) ex.each([&](C &c) { phase_dma_issue<Cfg>(c, a, ex.lds(), 0); });
+    }
     for (int it = 0; it < a.ppw; ++it) {
-        if ((((uint64_t) ex.block_y() * (uint32_t) a.ppw + (uint32_t) it) << a.log_up) >= a.batch) break;  // uniform
+        if (!group_valid(it)) break;
         ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, it); });
-        if constexpr (Cfg::DIRECT_LOAD) {
+        typename Cfg::W *const tile = Cfg::DMA ? ex.lds() + (it & 1) * Cfg::TILE_WORDS : ex.lds();
+        if constexpr (Cfg::DMA) {
+            if (it == 0) ex.each([&](C &) { phase_dma_wait<Cfg, true>(); });
+            else ex.each([&](C &) { phase_dma_wait<Cfg, false>(); });
+            if (group_valid(it + 1)) ex.each([&](C &c) { phase_dma_issue<Cfg>(c, a, ex.lds(), it + 1); });
+            ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, tile); });
+        } else if constexpr (Cfg::DIRECT_LOAD) {
             ex.each([&](C &c) { phase_load_direct<Cfg, FIRST>(c, a, it); });
         } else {
-            ex.each([&](C &c) { phase_linear<Cfg, true>(c, a, ex.lds(), it); });
+            ex.each([&](C &c) { phase_linear<Cfg, true>(c, a, tile, it); });
             ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
-            ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, ex.lds()); });
+            ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, tile); });
         }
         static_for<0, R>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
@@ -508,18 +571,18 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.each([&](C &c) { phase_compute<Cfg, r>(c, a); });
             if constexpr (k < R - 1) {
                 constexpr int rn = Cfg::INV ? r - 1 : r + 1;
-                ex.each([&](C &c) { phase_lds_write<Cfg, r>(c, ex.lds()); });
+                ex.each([&](C &c) { phase_lds_write<Cfg, r>(c, tile); });
                 ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
-                ex.each([&](C &c) { phase_lds_read<Cfg, rn>(c, ex.lds()); });
+                ex.each([&](C &c) { phase_lds_read<Cfg, rn>(c, tile); });
             }
         });
         if constexpr (Cfg::INV) ex.each([&](C &c) { phase_scale<Cfg>(c, a); });
         if constexpr (Cfg::DIRECT_STORE) {
             ex.each([&](C &c) { phase_store_direct<Cfg, LAST>(c, a, it); });
         } else {
-            ex.each([&](C &c) { phase_lds_write<Cfg, LAST>(c, ex.lds()); });
+            ex.each([&](C &c) { phase_lds_write<Cfg, LAST>(c, tile); });
             ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
-            ex.each([&](C &c) { phase_linear<Cfg, false>(c, a, ex.lds(), it); });
+            ex.each([&](C &c) { phase_linear<Cfg, false>(c, a, tile, it); });
         }
         if constexpr (ANY_LDS) {
             ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});  // next iteration rewrites the tile

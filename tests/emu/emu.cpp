@@ -26,7 +26,7 @@ struct EmuExec {
     std::vector<Ctx<Cfg>> ctx;
     std::vector<typename Cfg::W> tile;
     uint32_t bx, by;
-    EmuExec() : ctx(NT), tile(Cfg::LDS_WORDS) {}
+    EmuExec() : ctx(NT), tile(Cfg::DMA ? 2 * Cfg::TILE_WORDS : Cfg::LDS_WORDS) {}
     void init(const PassArgs<Cfg> &a) {
         for (int t = 0; t < NT; t++) phase_init<Cfg>(ctx[t], a, (uint32_t) t, bx, by);
     }

@@ -17,7 +17,9 @@ SGPR producer->consumer pair at least 3 slots apart, so no s_nop is needed.
 Register use inside a statement: data words and 32-bit temporaries are compiler-allocated
 operands; the 64-bit products need aligned VGPR pairs whose halves are used separately, which
 inline-asm operands cannot express, so they live in fixed VGPRs v[108:127] (clobbers), and the
-carries in fixed SGPR pairs s[84:99] + vcc.
+carries in fixed SGPR pairs s[84:99] + vcc.  The s_or_b64 / s_andn2_b64 in the streams write
+SCC, so SCC is declared clobbered too (without it hipcc scheduled an s_add_u32 / s_addc_u32 pair
+across a statement and the carry was lost).
 """
 import sys
 
@@ -185,7 +187,7 @@ def emit(kind, nb, tw_constraint, vbase=108, suffix=""):
             outs += [f'[y0_{b}] "+v"(y0_{b})', f'[y1_{b}] "+v"(y1_{b})']
             outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("d0_", "d1_", "z0_", "z1_", "u0_", "u1_")]
         ins_ += [f'[t0_{b}] "{tw_constraint}"(t0_{b})', f'[t1_{b}] "{tw_constraint}"(t1_{b})']
-    clob = ['"vcc"'] + [f'"v{r}"' for r in range(vbase, vbase + 10 * nb)] + [f'"s{r}"' for r in range(84, 84 + 8 * nb)]
+    clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 10 * nb)] + [f'"s{r}"' for r in range(84, 84 + 8 * nb)]
     src.append("        : " + ", ".join(outs))
     src.append("        : " + ", ".join(ins_))
     src.append("        : " + ", ".join(clob) + ");")
