@@ -95,6 +95,13 @@ int ntt_make_roots(ntt_plan_t plan, uint64_t g, void *host_T);
  * (kind 0 = ntt_make_roots).  Returns NTT_E_ARG when N does not divide the order. */
 int ntt_make_table(ntt_plan_t plan, int kind, uint64_t g, void *host_T);
 
+/* The same tables generated ON THE DEVICE (no host table, no upload): one
+ * square-and-multiply per entry from w = g^((p-1)/N) (kind 0/1) or psi^-1 (kind 2), forward and
+ * inverse table in table form.  Equivalent to ntt_make_table + ntt_plan_set_twiddles. */
+int ntt_plan_generate_twiddles(ntt_plan_t plan, int kind, uint64_t g);
+/* Read back the plan's table as plain residues (inverse != 0: the T^-1 table). */
+int ntt_plan_get_twiddles(ntt_plan_t plan, int inverse, void *host_T);
+
 /* plan introspection (for harnesses): 0 logn, 1 word_bytes, 2 device,
  * 3 number of HBM passes of one forward transform, 4 has-inverse-table */
 int64_t ntt_plan_info(ntt_plan_t plan, int what);

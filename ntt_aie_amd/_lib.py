@@ -28,7 +28,7 @@ LAYOUT_AIE_BLOCK16 = 1
 # every symbol include/ntt_hip.h declares
 EXPORTS = (
     "ntt_version", "ntt_error_string", "ntt_device_count", "ntt_plan_create", "ntt_plan_destroy",
-    "ntt_plan_set_twiddles", "ntt_make_roots", "ntt_make_table", "ntt_plan_info", "ntt_forward",
+    "ntt_plan_set_twiddles", "ntt_make_roots", "ntt_make_table", "ntt_plan_generate_twiddles", "ntt_plan_get_twiddles", "ntt_plan_info", "ntt_forward",
     "ntt_forward_profile", "ntt_inverse", "ntt_pointwise_mul", "ntt_polymul_negacyclic", "ntt_forward_stages",
 )
 
@@ -69,6 +69,8 @@ def lib() -> C.CDLL:
         L.ntt_plan_set_twiddles.argtypes = [vp, vp]
         L.ntt_make_roots.argtypes = [vp, u64, vp]
         L.ntt_make_table.argtypes = [vp, C.c_int, u64, vp]
+        L.ntt_plan_generate_twiddles.argtypes = [vp, C.c_int, u64]
+        L.ntt_plan_get_twiddles.argtypes = [vp, C.c_int, vp]
         L.ntt_plan_info.restype = C.c_int64
         L.ntt_plan_info.argtypes = [vp, C.c_int]
         L.ntt_forward.argtypes = [vp, vp, vp, sz, C.c_int, vp]

@@ -39,6 +39,11 @@ hipError_t launch_pointwise_gl(const void *a, const void *b, void *c, size_t cou
 hipError_t launch_pointwise_m32(const void *a, const void *b, void *c, size_t count, uint32_t p,
                                 uint32_t pinv, uint32_t r2, uint32_t scale, hipStream_t s);
 
+// device-side table generation (no host upload): T[i] = base^e_kind(i), table form
+hipError_t launch_gen_table_gl(void *T, int logn, int kind, uint64_t base_m, uint64_t one_m, hipStream_t s);
+hipError_t launch_gen_table_m32(void *T, int logn, int kind, uint32_t base_m, uint32_t one_m, uint32_t p,
+                                uint32_t pinv, uint32_t r2, hipStream_t s);
+
 // one stage of the network, one thread per butterfly (bring-up path, test_stage hook)
 hipError_t launch_stage_gl(void *data, const void *tw, int n, int stage, size_t batch, hipStream_t s);
 hipError_t launch_stage_m32(void *data, const void *tw, int n, int stage, size_t batch, uint32_t p,

@@ -66,6 +66,40 @@ __global__ __launch_bounds__(256) void stage_kernel(typename F::W *data, const t
     }
 }
 
+// T[i] = base^e(i) in table (Montgomery) form, e(i) by the table rule (plan.h:make_table):
+//   kind 0: e = i                         (src/test.cpp:27-32: natural-order powers)
+//   kind 1: e = bitrev_{log2 h}(i - h) * N/(2h), h = 2^floor(log2 i)      (cyclic)
+//   kind 2: e = bitrev_{logN}(i)                                          (negacyclic, base = psi^-1)
+// Square-and-multiply per entry: log2(N) products, the whole table in one launch -- no host upload.
+template <class F>
+__global__ __launch_bounds__(256) void gen_table_kernel(typename F::W *T, int logn, int kind,
+                                                        typename F::W base_m, typename F::W one_m, F f) {
+    using W = typename F::W;
+    const uint32_t N = 1u << logn;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        uint32_t e = i;
+        if (kind == 1) {
+            if (i == 0) {
+                e = 0;
+            } else {
+                const int lh = 31 - __clz(i);
+                const uint32_t idx = i - (1u << lh);
+                const uint32_t rev = lh ? (__brev(idx) >> (32 - lh)) : 0u;
+                e = rev << (logn - lh - 1);
+            }
+        } else if (kind == 2) {
+            e = __brev(i) >> (32 - logn);
+        }
+        W r = one_m, b = base_m;
+        while (e) {
+            if (e & 1u) r = f.mul(r, b);
+            b = f.mul(b, b);
+            e >>= 1;
+        }
+        T[i] = r;
+    }
+}
+
 inline unsigned grid_for(size_t work) {
     size_t g = (work + 255) / 256;
     if (g > 8192) g = 8192;  // 256 CUs x 8 x 4: grid-stride the rest
@@ -90,6 +124,19 @@ hipError_t launch_pointwise_m32(const void *a, const void *b, void *c, size_t co
     hipLaunchKernelGGL(pointwise_kernel<FieldM32>, dim3(grid_for(count / 4)), dim3(256), 0, s,
                        (const uint32_t *) a, (const uint32_t *) b, (uint32_t *) c, count,
                        FieldM32{p, pinv, r2}, scale, scale != 1 ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_table_gl(void *T, int logn, int kind, uint64_t base_m, uint64_t one_m, hipStream_t s) {
+    hipLaunchKernelGGL(gen_table_kernel<FieldGL>, dim3(grid_for((size_t) 1 << logn)), dim3(256), 0, s,
+                       (uint64_t *) T, logn, kind, base_m, one_m, FieldGL{});
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_table_m32(void *T, int logn, int kind, uint32_t base_m, uint32_t one_m, uint32_t p,
+                                uint32_t pinv, uint32_t r2, hipStream_t s) {
+    hipLaunchKernelGGL(gen_table_kernel<FieldM32>, dim3(grid_for((size_t) 1 << logn)), dim3(256), 0, s,
+                       (uint32_t *) T, logn, kind, base_m, one_m, FieldM32{p, pinv, r2});
     return hipGetLastError();
 }
 

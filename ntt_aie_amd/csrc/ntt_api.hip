@@ -167,7 +167,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     }
     pl->ninv_plain = powmod((p + 1) / 2, (uint64_t) logn, p);  // (2^-1)^logn; p + 1 < 2^64
     pl->scale_tf = to_table_form(pl->ninv_plain, p, word_bytes);
-    pl->target_wgs = 2048;
+    pl->target_wgs = 8192;  // workgroups per launch the batch loop is sized for (sweep: profiles/)
     if (const char *e = getenv("NTT_TARGET_WGS")) {
         long v = atol(e);
         if (v > 0 && v < (1 << 24)) pl->target_wgs = (uint32_t) v;
@@ -241,6 +241,61 @@ int ntt_make_table(ntt_plan_t pl, int kind, uint64_t g, void *host_T) {
     for (uint64_t i = 0; i < N; i++) {
         if (pl->word_bytes == 4) ((uint32_t *) host_T)[i] = (uint32_t) T[i];
         else ((uint64_t *) host_T)[i] = T[i];
+    }
+    return NTT_OK;
+}
+
+int ntt_plan_generate_twiddles(ntt_plan_t pl, int kind, uint64_t g) {
+    if (!pl || kind < 0 || kind > 2) return NTT_E_ARG;
+    const uint64_t N = 1ull << pl->logn, p = pl->p;
+    uint64_t base;
+    if (kind == 2) {
+        if ((p - 1) % (2 * N)) return NTT_E_ARG;
+        base = powmod(powmod(g, (p - 1) / (2 * N), p), p - 2, p);  // psi^-1
+    } else {
+        if (kind == 1 && (p - 1) % N) return NTT_E_ARG;
+        base = powmod(g, (p - 1) / N, p);                           // w (integer division, src/test.cpp:28)
+    }
+    if (base == 0) return NTT_E_NOTINVERTIBLE;
+    const uint64_t base_inv = powmod(base, p - 2, p);
+    const int wb = pl->word_bytes;
+    const uint64_t one_m = to_table_form(1 % p, p, wb);
+    DeviceGuard g_(pl->device);
+    if (g_.err != hipSuccess) return (int) g_.err;
+    hipError_t e;
+    if (wb == 8) {
+        e = ntt::launch_gen_table_gl(pl->d_tw_fwd, pl->logn, kind, to_table_form(base, p, 8), one_m, nullptr);
+        if (e == hipSuccess)
+            e = ntt::launch_gen_table_gl(pl->d_tw_inv, pl->logn, kind, to_table_form(base_inv, p, 8), one_m, nullptr);
+    } else {
+        e = ntt::launch_gen_table_m32(pl->d_tw_fwd, pl->logn, kind, (uint32_t) to_table_form(base, p, 4),
+                                      (uint32_t) one_m, (uint32_t) p, pl->pinv, pl->r2, nullptr);
+        if (e == hipSuccess)
+            e = ntt::launch_gen_table_m32(pl->d_tw_inv, pl->logn, kind, (uint32_t) to_table_form(base_inv, p, 4),
+                                          (uint32_t) one_m, (uint32_t) p, pl->pinv, pl->r2, nullptr);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) return (int) e;
+    pl->has_table = true;
+    pl->has_inv = true;  // every entry is a power of a unit
+    return NTT_OK;
+}
+
+int ntt_plan_get_twiddles(ntt_plan_t pl, int inverse, void *host_T) {
+    if (!pl || !host_T) return NTT_E_ARG;
+    if (!pl->has_table) return NTT_E_NOTABLE;
+    if (inverse && !pl->has_inv) return NTT_E_NOTINVERTIBLE;
+    DeviceGuard g_(pl->device);
+    if (g_.err != hipSuccess) return (int) g_.err;
+    hipError_t e = hipMemcpy(host_T, inverse ? pl->d_tw_inv : pl->d_tw_fwd, table_bytes(pl), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return (int) e;
+    // table (Montgomery) form -> plain residues: x * R^-1
+    const size_t N = (size_t) 1 << pl->logn;
+    const uint64_t p = pl->p;
+    const uint64_t rinv = powmod(to_table_form(1 % p, p, pl->word_bytes), p - 2, p);
+    for (size_t i = 0; i < N; i++) {
+        if (pl->word_bytes == 4) ((uint32_t *) host_T)[i] = (uint32_t) mulmod(((uint32_t *) host_T)[i], rinv, p);
+        else ((uint64_t *) host_T)[i] = mulmod(((uint64_t *) host_T)[i], rinv, p);
     }
     return NTT_OK;
 }

@@ -84,6 +84,16 @@ class NTTPlan:
         check(_lib.lib().ntt_plan_set_twiddles(self._h, T.ctypes.data), "ntt_plan_set_twiddles")
         self.table = T
 
+    def generate_twiddles(self, kind: int, g: int) -> None:
+        """Make the table (and its inverse) on the device: no host table, no upload."""
+        check(_lib.lib().ntt_plan_generate_twiddles(self._h, kind, g), "ntt_plan_generate_twiddles")
+        self.table = None
+
+    def get_twiddles(self, inverse: bool = False) -> np.ndarray:
+        T = np.empty(self.n, dtype=_np_dtype(self.word_bytes))
+        check(_lib.lib().ntt_plan_get_twiddles(self._h, int(inverse), T.ctypes.data), "ntt_plan_get_twiddles")
+        return T
+
     @property
     def hbm_passes(self) -> int:
         return int(_lib.lib().ntt_plan_info(self._h, 3))

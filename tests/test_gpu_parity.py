@@ -238,3 +238,56 @@ def test_config4_n20_polymul_sampled(eng, oracle):
     c = eng.to_host(pl.polymul_negacyclic(eng.to_device(a, "cuda:0"), eng.to_device(b, "cuda:0")))
     A, B = oracle.intt(a[:1], T, p, nthreads=8), oracle.intt(b[:1], T, p, nthreads=8)
     assert np.array_equal(c[:1], oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p))
+
+
+def test_reference_test_procedure(eng, oracle, tmp_path):
+    """the reference's own test (src/test.cpp:137-247: logN=11, p=3329, g=3,
+    a[i]=i, 10 timed launches, block-order compare, PASS/FAIL exit code) against the engine."""
+    import io
+
+    from ntt_aie_amd import host
+
+    n, p, g = 2048, 3329, 3
+    T = oracle.make_roots(n, p, g, 4)
+    want = oracle.ntt(np.arange(n, dtype=np.uint32), T, p)
+    assert np.array_equal(host.block_order(want), oracle.block16(want))
+    buf = io.StringIO()
+    rc, times = host.reference_procedure(expected_natural=want, out=buf)
+    text = buf.getvalue()
+    assert rc == 0 and "PASS!" in text and len(times) == 10
+    assert len([l for l in text.splitlines() if l.strip().isdigit()]) == 10
+    bad = want.copy()
+    bad[5] ^= 1
+    rc, _ = host.reference_procedure(expected_natural=bad, out=io.StringIO())
+    assert rc == 1
+    path = tmp_path / "ntt_mi355x_logn11.csv"
+    host.write_exectime_csv(str(path), times)
+    assert len(path.read_text().split()) == 10
+    assert host.trimmed_mean([1996, 317, 293, 300, 310]) == pytest.approx((317 + 300 + 310) / 3)
+    assert host.kerneltime_row(2048, 14.3748) == "2048 , 14.37480"
+    assert host.efficiency(2048, 14.3748, 88.0) == pytest.approx(5.5 * 2048 * 11 / 14.3748e-6 / 88e9)
+
+
+def test_device_generated_tables(eng, oracle):
+    """tables made on the device equal the host rule, word for word, and so do
+    the transforms that use them."""
+    for wb, p, g in [(8, GOLD, 7), (4, 998244353, 3), (4, 3329, 3)]:
+        dt = np.uint32 if wb == 4 else np.uint64
+        for logn in (4, 11, 16):
+            n = 1 << logn
+            pl = eng.NTTPlan(logn, p, wb, 0)
+            for kind in (0, 1, 2):
+                try:
+                    T = pl.make_table(kind, g)
+                except eng.NTTError:
+                    with pytest.raises(eng.NTTError):
+                        pl.generate_twiddles(kind, g)
+                    continue
+                pl.generate_twiddles(kind, g)
+                assert np.array_equal(pl.get_twiddles(), T), (wb, logn, kind)
+                Ti = pl.get_twiddles(inverse=True).astype(object)
+                assert all((int(x) * int(y)) % p == 1 for x, y in zip(T[1:64], Ti[1:64]))
+                a = _rand(2, n, p, dt, kind)
+                f = pl.forward(eng.to_device(a, "cuda:0"))
+                assert np.array_equal(eng.to_host(f), oracle.ntt(a, T, p))
+                assert np.array_equal(eng.to_host(pl.inverse(f)), a)
