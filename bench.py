@@ -34,7 +34,7 @@ def synth_batch(torch, batch, n, device, seed):
     return (hi << 32) | lo
 
 
-def cpu_baseline(logn, p, table, budget_s=12.0):
+def cpu_baseline(logn, p, table, cpu_seconds=20.0):
     """Oracle (port of the reference CPU verification path) on the host cores, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
@@ -49,8 +49,8 @@ def cpu_baseline(logn, p, table, budget_s=12.0):
     O.ntt(probe, table, p, nthreads=1)
     t1 = (time.perf_counter() - t0) / 2
     rate_1 = 1.0 / t1
-    # all cores: sample sized for ~budget_s/2 of wall time if scaling were perfect, capped
-    sample = int(max(cores * 2, min(cores * 64, (budget_s / 2) / t1 * cores)))
+    # bounded sample: about `cpu_seconds` of CPU work in total, spread over the host threads
+    sample = int(max(cores * 2, min(16384, cpu_seconds / t1)))
     a = rng.integers(0, 2**63, size=(sample, n), dtype=np.uint64)
     t0 = time.perf_counter()
     O.ntt(a, table, p, nthreads=cores)
@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--batch", type=int, default=4096, help="polynomials per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even for one rank: exercises the twiddle broadcast path")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,8 +88,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ntt_aie_amd.dist import ShardedNTT
@@ -99,7 +103,8 @@ def main():
     y = torch.empty_like(x)
     stream = torch.cuda.current_stream()
 
-    for _ in range(args.warmup):
+    PREWARM = 8  # untimed, before the W warm-up steps: first touches of 4 GiB (TLB) and the clock ramp
+    for _ in range(PREWARM + args.warmup):
         plan.forward(x, y, stream=stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -123,7 +128,7 @@ def main():
     out = {
         "metric": "forward-NTT/s, N=2^%d 64-bit Goldilocks prime, batch=%d per GPU" % (logn, batch),
         "value": value, "unit": "NTT/s", "butterflies_per_s": value * (n // 2) * logn,
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": "N=2^%d forward NTT, p=2^64-2^32+1, make_roots table g=7, batch=%d per GPU, "
@@ -166,7 +171,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(logn, p, eng.table)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -143,7 +143,8 @@ struct PassArgs {
     int log_up;
     int layout;    // transform-domain layout; honoured by the pass holding the top stage
     int do_scale;  // inverse: multiply by `scale` (N^-1, table form) after the last round
-    int dbg;       // timing experiments only (bit 0: every iteration re-reads polynomial group 0)
+    int dbg;       // timing experiments only: 1 = every iteration re-reads polynomial group 0,
+                   // 2 = skip the direct stores, 4 = every iteration stores to polynomial group 0
     W scale;
 };
 
@@ -186,11 +187,12 @@ NTT_HD uint32_t lane_word(const PassArgs<Cfg> &a, int b0, uint32_t q, uint32_t c
 
 // uniform part of the word index: workgroup tile origin + polynomial group of iteration `it`
 template <class Cfg>
-NTT_HD size_t uniform_word(const Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
+NTT_HD size_t uniform_word(const Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it, int dbg_bit = 1) {
     const int log_ltb = Cfg::CONTIG ? 0 : a.s0 - Cfg::LOG_C - a.log_ul;
     const uint32_t ltb = Cfg::CONTIG ? 0u : (c.bx & ((1u << log_ltb) - 1u));
     const uint32_t hb = Cfg::CONTIG ? c.bx : (c.bx >> log_ltb);
-    const size_t pg = (a.dbg & 1) ? 0 : (size_t) c.by * (uint32_t) a.ppw + (uint32_t) it;
+    size_t pg = (a.dbg & dbg_bit) ? 0 : (size_t) c.by * (uint32_t) a.ppw + (uint32_t) it;
+    if (a.dbg & 8) pg &= (size_t) ((a.dbg >> 4) - 1);  // confine traffic to the first (dbg >> 4) polynomial groups
     return ((size_t) hb << (a.log_uh + a.s0 + Cfg::LOG_M)) + ((size_t) ltb << (a.log_ul + Cfg::LOG_C)) +
            (pg << (a.log_up + a.n));
 }
@@ -337,8 +339,8 @@ NTT_HD void phase_load_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
 template <class Cfg, int r>
 NTT_HD void phase_store_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     using W = typename Cfg::W;
-    W *ubase = a.out + uniform_word<Cfg>(c, a, it);
-    if (!c.active) return;
+    W *ubase = a.out + uniform_word<Cfg>(c, a, it, 4);
+    if (!c.active || (a.dbg & 2)) return;
 #if defined(__HIP_DEVICE_COMPILE__)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) ubase, 0, -1, 0x00020000);
     const uint32_t voff = c.lane_st * (uint32_t) sizeof(W);
@@ -477,6 +479,28 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
         constexpr int t = m - b0;
         constexpr int off = Cfg::E - (Cfg::E >> t);
 #if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (std::is_same<typename Cfg::F, FieldM32>::value && Cfg::E >= 8) {
+            // four independent butterflies per statement; p < 2^31 takes the carry-free v_min_u32 form
+            const bool small_p = f.p < 0x80000000u;  // kernel argument: wave-uniform branch
+            static_for<0, Cfg::E / 8>([&](auto pp) {
+                constexpr int k0 = 4 * decltype(pp)::value;
+                constexpr int e0 = (((k0 + 0) >> t) << (t + 1)) | ((k0 + 0) & ((1 << t) - 1));
+                constexpr int e1 = (((k0 + 1) >> t) << (t + 1)) | ((k0 + 1) & ((1 << t) - 1));
+                constexpr int e2 = (((k0 + 2) >> t) << (t + 1)) | ((k0 + 2) & ((1 << t) - 1));
+                constexpr int e3 = (((k0 + 3) >> t) << (t + 1)) | ((k0 + 3) & ((1 << t) - 1));
+                constexpr int S = 1 << t;
+                const W T0 = c.tw[r][off + (e0 >> (t + 1))], T1 = c.tw[r][off + (e1 >> (t + 1))];
+                const W T2 = c.tw[r][off + (e2 >> (t + 1))], T3 = c.tw[r][off + (e3 >> (t + 1))];
+                if (small_p) {
+                    if constexpr (!Cfg::INV) m32_fwd4_small(c.x[e0], c.x[e0 | S], T0, c.x[e1], c.x[e1 | S], T1, c.x[e2], c.x[e2 | S], T2, c.x[e3], c.x[e3 | S], T3, f.p, f.pinv);
+                    else m32_inv4_small(c.x[e0], c.x[e0 | S], T0, c.x[e1], c.x[e1 | S], T1, c.x[e2], c.x[e2 | S], T2, c.x[e3], c.x[e3 | S], T3, f.p, f.pinv);
+                } else {
+                    if constexpr (!Cfg::INV) m32_fwd4_any(c.x[e0], c.x[e0 | S], T0, c.x[e1], c.x[e1 | S], T1, c.x[e2], c.x[e2 | S], T2, c.x[e3], c.x[e3 | S], T3, f.p, f.pinv);
+                    else m32_inv4_any(c.x[e0], c.x[e0 | S], T0, c.x[e1], c.x[e1 | S], T1, c.x[e2], c.x[e2 | S], T2, c.x[e3], c.x[e3 | S], T3, f.p, f.pinv);
+                }
+            });
+            return;
+        }
         if constexpr (std::is_same<typename Cfg::F, FieldGL>::value && Cfg::E >= 4) {
             // butterfly k of this stage: low element index with bit t cleared
             static_for<0, Cfg::E / 4>([&](auto pp) {

@@ -32,7 +32,7 @@ def broadcast_table(table: np.ndarray | None, n: int, word_bytes: int, src: int 
     """
     np_dt = np.uint32 if word_bytes == 4 else np.uint64
     t_dt = torch.int32 if word_bytes == 4 else torch.int64
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         if table is None:
             raise ValueError("single process: the table must be supplied")
         return np.ascontiguousarray(table, dtype=np_dt)

@@ -106,6 +106,89 @@ def butterfly(kind, b, vbase=108):
     return ins
 
 
+def butterfly32(kind, b, small, vbase=96):
+    """4-byte-word Montgomery butterfly `b` (R = 2^32, twiddle in Montgomery form).
+    small = True: p < 2^31, conditional corrections by v_min_u32 (no carries, no SGPRs);
+    small = False: any odd p < 2^32, carries in SGPR pairs.  Operands: x y t (compiler),
+    temporaries a b c, scalars %[p] %[pinv]; the 64-bit product lives in a fixed VGPR pair."""
+    L = (f"v{vbase + 2 * b}", f"v{vbase + 2 * b + 1}")
+    LP = f"v[{vbase + 2 * b}:{vbase + 2 * b + 1}]"
+    sa, sb = f"s[{84 + 4 * b}:{85 + 4 * b}]", f"s[{86 + 4 * b}:{87 + 4 * b}]"
+
+    def o(name):
+        return f"%[{name}{b}]"
+
+    x, y, t, ta, tb, tc = o("x_"), o("y_"), o("t_"), o("a_"), o("b_"), o("c_")
+    P, PI = "%[p]", "%[pinv]"
+    ins = []
+
+    def add(u, v, out):  # out = (u + v) mod p ; clobbers ta, tb
+        if small:
+            ins.append(Ins(f"v_add_u32 {ta}, {u}, {v}", [u, v], [ta]))
+            ins.append(Ins(f"v_subrev_u32 {tb}, {P}, {ta}", [ta], [tb]))
+            ins.append(Ins(f"v_min_u32 {out}, {ta}, {tb}", [ta, tb], [out]))
+        else:
+            ins.append(Ins(f"v_add_co_u32 {ta}, {sa}, {u}, {v}", [u, v], [ta, sa]))
+            ins.append(Ins(f"v_subrev_co_u32 {tb}, {sb}, {P}, {ta}", [ta], [tb, sb]))
+            ins.append(Ins(f"s_orn2_b64 {sa}, {sa}, {sb}", [sa, sb], [sa], salu=True))  # carry | !borrow
+            ins.append(Ins(f"v_cndmask_b32 {out}, {ta}, {tb}, {sa}", [ta, tb, sa], [out]))
+
+    def sub(u, v, out, tmp):  # out = (u - v) mod p ; clobbers tmp
+        if small:
+            ins.append(Ins(f"v_sub_u32 {out}, {u}, {v}", [u, v], [out]))
+            ins.append(Ins(f"v_add_u32 {tmp}, {P}, {out}", [out], [tmp]))
+            ins.append(Ins(f"v_min_u32 {out}, {out}, {tmp}", [out, tmp], [out]))
+        else:
+            ins.append(Ins(f"v_sub_co_u32 {out}, {sb}, {u}, {v}", [u, v], [out, sb]))
+            ins.append(Ins(f"v_add_u32 {tmp}, {P}, {out}", [out], [tmp]))
+            ins.append(Ins(f"v_cndmask_b32 {out}, {out}, {tmp}, {sb}", [out, tmp, sb], [out]))
+
+    def mul(m, out, t1, t2):  # out = m * T * 2^-32 mod p ; clobbers t1, t2
+        ins.append(Ins(f"v_mad_u64_u32 {LP}, vcc, {m}, {t}, 0", [m, t], [L[0], L[1], "vcc"]))
+        ins.append(Ins(f"v_mul_lo_u32 {t1}, {L[0]}, {PI}", [L[0]], [t1]))
+        ins.append(Ins(f"v_mul_hi_u32 {t1}, {t1}, {P}", [t1], [t1]))
+        sub(L[1], t1, out, t2)
+
+    if kind == "fwd32":    # x' = x + y ; y' = (x - y) * T
+        sub(x, y, tc, ta)
+        add(x, y, x)
+        mul(tc, y, ta, tb)
+    elif kind == "inv32":  # w = y * T ; x' = x + w ; y' = x - w
+        mul(y, tc, ta, tb)
+        sub(x, tc, y, ta)
+        add(x, tc, x)
+    return ins
+
+
+def emit32(kind, nb, small, vbase=96):
+    lists = [butterfly32(kind, b, small, vbase) for b in range(nb)]
+    lines = schedule(lists)
+    nops = sum(1 for l in lines if l.startswith("s_nop"))
+    name = f"m32_{kind[:3]}{nb}_{'small' if small else 'any'}"
+    args = ", ".join(f"uint32_t &x{b}, uint32_t &y{b}, uint32_t t{b}" for b in range(nb))
+    src = [f"// {kind} x{nb} ({'p < 2^31' if small else 'any odd p < 2^32'}): {len(lines)} instructions, {nops} s_nop",
+           f"__device__ __forceinline__ void {name}({args}, uint32_t p, uint32_t pinv) {{"]
+    for b in range(nb):
+        src.append(f"    uint32_t a_{b}, b_{b}, c_{b};")
+    src.append("    asm volatile(")
+    for l in lines:
+        src.append(f'        "{l}\\n\\t"')
+    outs, ins_ = [], []
+    for b in range(nb):
+        outs += [f'[x_{b}] "+v"(x{b})', f'[y_{b}] "+v"(y{b})']
+        outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("a_", "b_", "c_")]
+        ins_ += [f'[t_{b}] "v"(t{b})']
+    ins_ += ['[p] "s"(p)', '[pinv] "s"(pinv)']
+    clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 2 * nb)]
+    if not small:
+        clob += [f'"s{r}"' for r in range(84, 84 + 4 * nb)]
+    src.append("        : " + ", ".join(outs))
+    src.append("        : " + ", ".join(ins_))
+    src.append("        : " + ", ".join(clob) + ");")
+    src.append("}")
+    return "\n".join(src), len(lines), nops
+
+
 def schedule(lists):
     """Merge instruction lists (each in program order) keeping dependencies; SGPR RAW pairs
     SGPR_DIST slots apart.  Returns lines (s_nop inserted only if unavoidable)."""
@@ -215,6 +298,12 @@ def main():
             txt, n, nops = emit(kind, 2, "v", vbase=76, suffix="_lo")  # for the radix-8 (light) kernels
             out.append(txt)
             out.append("")
+    for kind in ("fwd32", "inv32"):
+        for small in (True, False):
+            txt, n, nops = emit32(kind, 4, small)
+            out.append(txt)
+            out.append("")
+            print(f"{kind} x4 small={small}: {n} instructions, {nops} nops", file=sys.stderr)
     out += ["}  // namespace ntt", "#endif"]
     open(sys.argv[1] if len(sys.argv) > 1 else "ntt_aie_amd/csrc/gl_asm.h", "w").write("\n".join(out) + "\n")
 
