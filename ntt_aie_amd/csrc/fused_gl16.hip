@@ -1,0 +1,223 @@
+// fused_gl16.hip -- N = 2^16 Goldilocks forward transform as ONE persistent launch in which the
+// column pass (stages 8-15) reads what the CONTIG pass (stages 0-7) of the SAME XCD wrote a few
+// microseconds earlier, i.e. from that XCD's 4 MiB L2 instead of from HBM.
+//
+// Why: each of the two pass kernels already streams at the rate of a plain device copy
+// (DESIGN.md section 3.4); the remaining cost is that every coefficient crosses the fabric twice.
+//
+// Schedule (static, affinity-preserving so twiddles stay in registers):
+//   * every workgroup reads its XCC id (HW_REG_XCC_ID) and takes a slot on that XCD;
+//   * polynomial p belongs to XCD p mod 8;
+//   * slots   0..63  : 2 producer sets x 32 workgroups -- workgroup w runs the CONTIG radix-8 DMA
+//                      pass on hi-block w of every 2nd polynomial of its XCD and publishes it one
+//                      iteration later, per wave: counted vmcnt wait, agent-scope add on done[p];
+//   * slots  64..127 : 4 consumer sets x 16 workgroups -- workgroup v waits until done[p] == 128,
+//                      then runs the column pass on lo-tile v of every 4th polynomial of its XCD.
+// Producers never wait, so there is no deadlock; consumers spin with a bound and raise `status`
+// when it is hit (an XCD that received fewer than 128 resident workgroups).  The launch is always
+// followed by a one-thread check kernel and by the two ordinary pass kernels guarded by its verdict
+// (they return at once when the fused result is complete), so the stream-ordered result is correct
+// whatever the dispatcher does -- placement decides speed, never correctness.
+//
+// Same-XCD visibility: L1 is write-through and invalidated at kernel start; a consumer reads each
+// intermediate line exactly once, after the producers' stores were acknowledged by the shared L2
+// (s_waitcnt vmcnt(0) in every storing wave, then the barrier, then the counter add); the counter
+// itself is an agent-scope atomic polled with an agent-scope (L1-bypassing) load.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "pass.h"
+
+namespace ntt {
+namespace {
+
+constexpr int A_SETS = 2, B_SETS = 4;
+constexpr int A_TILES = 32;  // CONTIG radix-8 tiles (2048 words) per polynomial
+constexpr int B_TILES = 16;  // column tiles (256 rows x 16 columns) per polynomial
+constexpr int SLOTS = A_SETS * A_TILES + B_SETS * B_TILES;  // 128 per XCD = 4 workgroups per CU
+constexpr uint32_t SPIN_LIMIT = 400000;
+
+struct FusedCtl {  // device words, zeroed by hipMemsetAsync before every launch
+    uint32_t slots[8];
+    uint32_t status;  // != 0: a consumer gave up
+    uint32_t b_done;  // column tiles completed
+    uint32_t ok;      // written by the check kernel: 1 = fused result complete
+    uint32_t pad[5];
+    uint32_t done[1];  // [batch] producer arrivals per polynomial
+};
+
+using CfgA = PassCfg<FieldGL, 8, 0, true, false, 0xF, 3>;
+using CfgB = PassCfg<FieldGL, 8, LOG_COLS, false, false, 0xF>;
+constexpr int TILE_LDS_WORDS = 2 * CfgA::TILE_WORDS > CfgB::LDS_WORDS ? 2 * CfgA::TILE_WORDS : CfgB::LDS_WORDS;
+
+template <class Cfg, bool PRODUCER>
+struct FusedExec {
+    using W = typename Cfg::W;
+    Ctx<Cfg> ctx;
+    W *tile;
+    uint32_t *flag;  // one LDS word behind the tile
+    FusedCtl *ctl;
+    uint32_t bx, pg0;
+    int pg_stride;
+    bool nowait = false;
+
+    __device__ __forceinline__ void init(const PassArgs<Cfg> &a) {
+        phase_init<Cfg>(ctx, a, threadIdx.x, bx, 0);
+        ctx.pg_base = pg0;
+    }
+    template <class Fn>
+    __device__ __forceinline__ void each(Fn &&f) {
+        f(ctx);
+    }
+    __device__ __forceinline__ void sync(std::false_type) { __syncthreads(); }
+    __device__ __forceinline__ void sync(std::true_type) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ uint32_t pg_base() const { return ctx.pg_base; }
+    __device__ __forceinline__ W *lds() { return tile; }
+
+    __device__ __forceinline__ bool iter_begin(int it) {
+        if constexpr (PRODUCER) {
+            return true;
+        } else {
+            if (nowait) return true;
+            const uint32_t poly = pg0 + (uint32_t) it * (uint32_t) pg_stride;
+            if (threadIdx.x == 0) {
+                uint32_t spins = 0, ok = 1;
+                while (__hip_atomic_load(&ctl->done[poly], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (uint32_t) (A_TILES * 4)) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > SPIN_LIMIT) {
+                        __hip_atomic_fetch_or(&ctl->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = 0;
+                        break;
+                    }
+                }
+                *flag = ok;
+            }
+            __syncthreads();
+            const uint32_t ok = *flag;
+            __syncthreads();  // flag is rewritten next iteration
+            return ok != 0;
+        }
+    }
+    // Producer: wave-granular, deferred by one iteration so that nobody waits on a store:
+    // `s_waitcnt vmcnt(E)` lets this iteration's E stores fly and guarantees everything older --
+    // the previous polynomial's stores -- has been acknowledged by the XCD's L2; then one lane
+    // of the wave adds to that polynomial's counter (4 waves x 32 workgroups = 128 arrivals).
+    __device__ __forceinline__ void signal(int it) {
+        if ((threadIdx.x & 63u) == 0) {
+            const uint32_t poly = pg0 + (uint32_t) it * (uint32_t) pg_stride;
+            __hip_atomic_fetch_add(&ctl->done[poly], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __device__ __forceinline__ void iter_done(int it) {
+        if constexpr (PRODUCER) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::E) : "memory");
+            if (it >= 1) signal(it - 1);
+        }
+    }
+    __device__ __forceinline__ void pass_done(int completed) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (PRODUCER) {
+            if (completed >= 1) signal(completed - 1);
+        } else {
+            __syncthreads();
+            if (threadIdx.x == 0 && completed > 0)
+                __hip_atomic_fetch_add(&ctl->b_done, (uint32_t) completed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+};
+
+struct FusedArgs {
+    PassArgs<CfgA> a;
+    PassArgs<CfgB> b;
+    FusedCtl *ctl;
+    int dbg;  // experiments: 16 consumers do not wait, 32 producers exit, 64 consumers exit
+};
+
+__global__ __launch_bounds__(NT, 4) void fused_gl16_kernel(FusedArgs fa) {
+    __shared__ __attribute__((aligned(16))) uint64_t tile[TILE_LDS_WORDS + 2];
+    uint32_t *flag = reinterpret_cast<uint32_t *>(tile + TILE_LDS_WORDS);
+    uint32_t xcc_raw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_raw));
+    const uint32_t xcc = xcc_raw & 7u;
+    if (threadIdx.x == 0)
+        *flag = __hip_atomic_fetch_add(&fa.ctl->slots[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(*flag);  // workgroup-uniform, make it provable
+    __syncthreads();
+    if (slot >= (uint32_t) SLOTS) return;  // surplus workgroup on this XCD
+    if (slot < (uint32_t) (A_SETS * A_TILES)) {
+        if (fa.dbg & 32) return;
+        FusedExec<CfgA, true> ex;
+        ex.tile = tile;
+        ex.flag = flag;
+        ex.ctl = fa.ctl;
+        ex.bx = slot % A_TILES;
+        ex.pg0 = xcc + 8u * (slot / A_TILES);
+        ex.pg_stride = 8 * A_SETS;
+        fa.a.pg_stride = ex.pg_stride;
+        run_pass<CfgA>(ex, fa.a);
+    } else {
+        if (fa.dbg & 64) return;
+        const uint32_t s = slot - A_SETS * A_TILES;
+        FusedExec<CfgB, false> ex;
+        ex.nowait = (fa.dbg & 16) != 0;
+        ex.tile = tile;
+        ex.flag = flag;
+        ex.ctl = fa.ctl;
+        ex.bx = s % B_TILES;
+        ex.pg0 = xcc + 8u * (s / B_TILES);
+        ex.pg_stride = 8 * B_SETS;
+        fa.b.pg_stride = ex.pg_stride;
+        run_pass<CfgB>(ex, fa.b);
+    }
+}
+
+__global__ void fused_check_kernel(FusedCtl *ctl, uint32_t want_b) {
+    const uint32_t st = __hip_atomic_load(&ctl->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t bd = __hip_atomic_load(&ctl->b_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ctl->ok = (st == 0 && bd == want_b) ? 1u : 0u;
+}
+
+}  // namespace
+
+size_t fused_gl16_ctl_bytes(size_t max_batch) { return sizeof(FusedCtl) + max_batch * sizeof(uint32_t); }
+const void *fused_gl16_ok_word(const void *ctl) { return &((const FusedCtl *) ctl)->ok; }
+
+// in != out, natural layout, batch a multiple of 8.  Enqueues memset + fused + check; the caller
+// then enqueues the ordinary pass launches with skip_if = fused_gl16_ok_word(ctl).
+hipError_t launch_fused_gl16(const void *in, void *out, const void *tw, size_t batch, void *ctl_mem, hipStream_t s, int dbg) {
+    FusedCtl *ctl = (FusedCtl *) ctl_mem;
+    hipError_t e = hipMemsetAsync(ctl, 0, fused_gl16_ctl_bytes(batch), s);
+    if (e != hipSuccess) return e;
+    FusedArgs fa{};
+    fa.ctl = ctl;
+    fa.dbg = dbg;
+    fa.a.in = (const uint64_t *) in;
+    fa.a.out = (uint64_t *) out;
+    fa.a.tw = (const uint64_t *) tw;
+    fa.a.n = 16;
+    fa.a.s0 = 0;
+    fa.a.batch = (uint32_t) batch;
+    fa.a.ppw = (int) (batch / (8 * A_SETS)) + 1;
+    fa.a.log_ul = 0;
+    fa.a.log_uh = CfgA::LOG_U;  // 8 units of 256 words per workgroup
+    fa.a.log_up = 0;
+    fa.b.in = (const uint64_t *) out;
+    fa.b.out = (uint64_t *) out;
+    fa.b.tw = (const uint64_t *) tw;
+    fa.b.n = 16;
+    fa.b.s0 = 8;
+    fa.b.batch = (uint32_t) batch;
+    fa.b.ppw = (int) (batch / (8 * B_SETS)) + 1;
+    hipLaunchKernelGGL(fused_gl16_kernel, dim3(8 * SLOTS), dim3(NT), 0, s, fa);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fused_check_kernel, dim3(1), dim3(1), 0, s, ctl, (uint32_t) (batch * B_TILES));
+    return hipGetLastError();
+}
+
+}  // namespace ntt

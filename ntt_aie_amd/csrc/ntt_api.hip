@@ -46,6 +46,9 @@ struct ntt_plan {
     uint64_t ninv_plain;   // N^-1 plain
     uint32_t target_wgs;
     int dbg;
+    int fused;         // NTT_FUSED=1: N = 2^16 Goldilocks forward through the XCD-local fused launch
+    void *d_fused_ctl;  // counters of the fused launch (plan-owned)
+    size_t fused_max_batch;
     std::vector<PassDesc> passes;
 };
 
@@ -81,8 +84,19 @@ int check_io(const ntt_plan *pl, const void *a, const void *b, size_t batch) {
 
 int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int layout, hipStream_t s) {
     const void *src = d_in;
+    const void *skip_if = nullptr;
+    if (pl->d_fused_ctl && d_in != d_out && layout == NTT_LAYOUT_NATURAL && batch >= 64 && batch % 8 == 0 &&
+        batch <= pl->fused_max_batch) {
+        // one persistent XCD-local launch; the ordinary passes below then only run (device-side
+        // decision, no host sync) if its check kernel did not certify the result
+        hipError_t e = ntt::launch_fused_gl16(d_in, d_out, pl->d_tw_fwd, batch, pl->d_fused_ctl, s, pl->dbg);
+        if (e != hipSuccess) return (int) e;
+        skip_if = ntt::fused_gl16_ok_word(pl->d_fused_ctl);
+        if (pl->dbg & (16 | 32 | 64)) return NTT_OK;  // timing experiments: fused launch alone
+    }
     for (const PassDesc &pd : pl->passes) {
         ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
+        a.skip_if = skip_if;
         a.tw = pl->d_tw_fwd;
         a.layout = layout;
         hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_fwd(pd.contig, pd.log_m, a, s)
@@ -174,6 +188,10 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     }
     pl->dbg = 0;
     if (const char *e = getenv("NTT_DEBUG_FLAGS")) pl->dbg = atoi(e);
+    pl->fused = 0;
+    pl->d_fused_ctl = nullptr;
+    pl->fused_max_batch = 0;
+    if (const char *e = getenv("NTT_FUSED")) pl->fused = atoi(e);
     pl->passes = plan_passes(logn);
     DeviceGuard g(device);
     if (g.err != hipSuccess) {
@@ -182,8 +200,13 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     }
     hipError_t e = hipMalloc(&pl->d_tw_fwd, table_bytes(pl));
     if (e == hipSuccess) e = hipMalloc(&pl->d_tw_inv, table_bytes(pl));
+    if (e == hipSuccess && pl->fused && logn == 16 && word_bytes == 8) {
+        pl->fused_max_batch = (size_t) 1 << 20;
+        e = hipMalloc(&pl->d_fused_ctl, ntt::fused_gl16_ctl_bytes(pl->fused_max_batch));
+    }
     if (e != hipSuccess) {
         if (pl->d_tw_fwd) (void) hipFree(pl->d_tw_fwd);
+        if (pl->d_tw_inv) (void) hipFree(pl->d_tw_inv);
         delete pl;
         return (int) e;
     }
@@ -196,6 +219,7 @@ int ntt_plan_destroy(ntt_plan_t pl) {
     DeviceGuard g(pl->device);
     if (pl->d_tw_fwd) (void) hipFree(pl->d_tw_fwd);
     if (pl->d_tw_inv) (void) hipFree(pl->d_tw_inv);
+    if (pl->d_fused_ctl) (void) hipFree(pl->d_fused_ctl);
     delete pl;
     return NTT_OK;
 }
@@ -310,8 +334,17 @@ int64_t ntt_plan_info(ntt_plan_t pl, int what) {
         case 2: return pl->device;
         case 3: return (int64_t) pl->passes.size();
         case 4: return pl->has_inv ? 1 : 0;
-        default: return NTT_E_ARG;
+        case 5: return pl->d_fused_ctl ? 1 : 0;
+        default: break;
     }
+    if (what >= 16 && what < 16 + 12 && pl->d_fused_ctl) {  // diagnostics: words of the last fused launch (blocking)
+        uint32_t w[12];
+        DeviceGuard g(pl->device);
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(w, pl->d_fused_ctl, sizeof(w), hipMemcpyDeviceToHost) != hipSuccess)
+            return NTT_E_ARG;
+        return w[what - 16];  // 0-7 slots per XCC, 8 status, 9 b_done, 10 ok
+    }
+    return NTT_E_ARG;
 }
 
 int ntt_forward(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int out_layout, void *stream) {

@@ -124,7 +124,8 @@ constexpr int contig_preload_mask(int log_m, int word_bytes, int log_e = 4) {
     if (word_bytes == 4) return 0xF;
     if (rounds <= 1) return 0xF;
     if (rounds == 2) return NTT_CONTIG_GL_MASK2;
-    return 0x0;
+    // three rounds: only the outermost one stays resident, and only when it is wave-uniform (SGPRs)
+    return log_m == 12 ? 0x4 : 0x0;
 }
 
 template <class Cfg>
@@ -143,6 +144,8 @@ struct PassArgs {
     int log_up;
     int layout;    // transform-domain layout; honoured by the pass holding the top stage
     int do_scale;  // inverse: multiply by `scale` (N^-1, table form) after the last round
+    int pg_stride;           // polynomial-group step per iteration (1 for the plain launches)
+    const uint32_t *skip_if; // non-null: every workgroup returns at once when *skip_if != 0 (guarded fallback)
     int dbg;       // timing experiments only: 1 = every iteration re-reads polynomial group 0,
                    // 2 = skip the direct stores, 4 = every iteration stores to polynomial group 0
     W scale;
@@ -154,6 +157,7 @@ struct Ctx {
     W x[Cfg::E];
     W tw[Cfg::R][Cfg::E > 1 ? Cfg::E - 1 : 1];
     uint32_t tid, bx, by;
+    uint32_t pg_base;        // first polynomial group of this workgroup (by * ppw for the plain launches)
     uint32_t q, hi;          // mid-thread index, hi value (twiddle addressing)
     uint32_t up;             // polynomial sub-index inside the workgroup
     uint32_t lane_ld, lane_st;       // lane part of the global word index (first / last round)
@@ -191,7 +195,7 @@ NTT_HD size_t uniform_word(const Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it, in
     const int log_ltb = Cfg::CONTIG ? 0 : a.s0 - Cfg::LOG_C - a.log_ul;
     const uint32_t ltb = Cfg::CONTIG ? 0u : (c.bx & ((1u << log_ltb) - 1u));
     const uint32_t hb = Cfg::CONTIG ? c.bx : (c.bx >> log_ltb);
-    size_t pg = (a.dbg & dbg_bit) ? 0 : (size_t) c.by * (uint32_t) a.ppw + (uint32_t) it;
+    size_t pg = (a.dbg & dbg_bit) ? 0 : (size_t) c.pg_base + (size_t) it * (uint32_t) a.pg_stride;
     if (a.dbg & 8) pg &= (size_t) ((a.dbg >> 4) - 1);  // confine traffic to the first (dbg >> 4) polynomial groups
     return ((size_t) hb << (a.log_uh + a.s0 + Cfg::LOG_M)) + ((size_t) ltb << (a.log_ul + Cfg::LOG_C)) +
            (pg << (a.log_up + a.n));
@@ -199,9 +203,9 @@ NTT_HD size_t uniform_word(const Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it, in
 
 template <class Cfg, int r>
 constexpr bool tw_uniform() {
-    // column pass with one unit per workgroup, outermost window: the twiddle index has no
-    // lane-dependent part, so the table entries live in SGPRs
-    return !Cfg::CONTIG && Cfg::LOG_U == 0 && (Cfg::win(r) + Cfg::LOG_E >= Cfg::LOG_M);
+    // one unit per workgroup, outermost window: the twiddle index has no lane-dependent part,
+    // so the table entries live in SGPRs (column passes of 8 stages, CONTIG passes of 12)
+    return Cfg::LOG_U == 0 && (Cfg::win(r) + Cfg::LOG_E >= Cfg::LOG_M) && sizeof(typename Cfg::W) == 8;
 }
 
 // ---- phases -------------------------------------------------------------------
@@ -237,6 +241,7 @@ NTT_HD void phase_init(Ctx<Cfg> &c, const PassArgs<Cfg> &a, uint32_t tid, uint32
     c.tid = tid;
     c.bx = bx;
     c.by = by;
+    c.pg_base = by * (uint32_t) a.ppw;
     const uint32_t col = tid & (Cfg::C - 1);
     c.q = (tid >> Cfg::LOG_C) & ((1u << Cfg::LOG_Q) - 1u);
     const uint32_t u = Cfg::LOG_U == 0 ? 0u : (tid >> (Cfg::LOG_C + Cfg::LOG_Q));
@@ -268,7 +273,7 @@ template <class Cfg>
 NTT_HD void phase_begin_iter(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     // run_pass() stops at the first polynomial group past the batch, so a lane can only be
     // inactive when several polynomials share one workgroup (log_up > 0: ragged tail)
-    const uint32_t poly = ((c.by * (uint32_t) a.ppw + (uint32_t) it) << a.log_up) | c.up;
+    const uint32_t poly = ((c.pg_base + (uint32_t) it * (uint32_t) a.pg_stride) << a.log_up) | c.up;
     c.active = Cfg::LOG_U == 0 ? true : poly < a.batch;
 }
 
@@ -374,7 +379,7 @@ NTT_HD void phase_linear(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *l
     constexpr int ITER = Cfg::E / V;
     using Ch = Chunk<W, V>;
     const size_t tile0 = uniform_word<Cfg>(c, a, it);
-    const uint32_t pg0 = (c.by * (uint32_t) a.ppw + (uint32_t) it) << a.log_up;
+    const uint32_t pg0 = (c.pg_base + (uint32_t) it * (uint32_t) a.pg_stride) << a.log_up;
     // wave w stages its own contiguous 64*E words: 1 KiB per wave-instruction, lanes along chunks
     const uint32_t wbase = (c.tid >> 6) << (6 + Cfg::LOG_E);
     const uint32_t lbase = Cfg::lds_index(wbase + (c.tid & 63u) * V);
@@ -568,13 +573,15 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     constexpr bool ANY_LDS = R > 1 || !Cfg::DIRECT_LOAD || !Cfg::DIRECT_STORE;
     ex.init(a);
     auto group_valid = [&](int it) {  // uniform: does polynomial group `it` of this workgroup exist
-        return it < a.ppw && (((uint64_t) ex.block_y() * (uint32_t) a.ppw + (uint32_t) it) << a.log_up) < a.batch;
+        return it < a.ppw && (((uint64_t) ex.pg_base() + (uint64_t) it * (uint32_t) a.pg_stride) << a.log_up) < a.batch;
     };
     if constexpr (Cfg::DMA) {
         if (group_valid(0)) ex.each([&](C &c) { phase_dma_issue<Cfg>(c, a, ex.lds(), 0); });
     }
+    int completed = 0;
     for (int it = 0; it < a.ppw; ++it) {
         if (!group_valid(it)) break;
+        if (!ex.iter_begin(it)) break;  // fused schedule: wait for the producer of this polynomial (uniform)
         ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, it); });
         typename Cfg::W *const tile = Cfg::DMA ? ex.lds() + (it & 1) * Cfg::TILE_WORDS : ex.lds();
         if constexpr (Cfg::DMA) {
@@ -608,10 +615,13 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
             ex.each([&](C &c) { phase_linear<Cfg, false>(c, a, tile, it); });
         }
+        ex.iter_done(it);  // fused schedule: publish the previous polynomial's tile
+        ++completed;
         if constexpr (ANY_LDS) {
             ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});  // next iteration rewrites the tile
         }
     }
+    ex.pass_done(completed);
 }
 
 // ---- launch geometry shared by host planner and host model ---------------------

@@ -40,7 +40,10 @@ struct EmuExec {
     }
     template <class B>
     void sync(B) {}
-    uint32_t block_y() const { return by; }
+    uint32_t pg_base() const { return ctx[0].pg_base; }
+    bool iter_begin(int) { return true; }
+    void iter_done(int) {}
+    void pass_done(int) {}
     typename Cfg::W *lds() { return tile.data(); }
 };
 
@@ -82,6 +85,8 @@ int run_cfg(const Erased &e) {
     a.do_scale = e.do_scale;
     a.scale = (W) e.scale;
     a.dbg = 0;
+    a.pg_stride = 1;
+    a.skip_if = nullptr;
     PassGeom g = pass_geometry(e.n, e.s0, Cfg::LOG_M, Cfg::LOG_C, Cfg::LOG_U, Cfg::CONTIG, e.batch, e.target_wgs);
     a.ppw = g.ppw;
     a.log_ul = g.log_ul;

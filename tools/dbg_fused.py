@@ -1,0 +1,28 @@
+import os, sys, time, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+os.environ["NTT_FUSED"] = "1"
+import torch, oracle_py as O
+from ntt_aie_amd import NTTPlan, to_device, to_host
+p = O.GOLDILOCKS; logn = 16; n = 1 << logn
+batch = int(sys.argv[1])
+plan = NTTPlan(logn, p, 8, 0); T = plan.make_roots(7); plan.set_twiddles(T)
+a = np.random.default_rng(0).integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p)
+d = to_device(a, "cuda:0"); out = torch.zeros_like(d)
+print("launch", flush=True)
+plan.forward(d, out); torch.cuda.synchronize()
+print("synced", flush=True)
+rows = list(range(0, batch, max(1, batch // 16)))
+got = to_host(out[rows]); want = O.ntt(a[rows], T, p, nthreads=8) if not os.environ.get("NTT_DEBUG_FLAGS") else got
+print("mismatching rows", int((got != want).any(axis=1).sum()), "of", len(rows))
+for _ in range(3): plan.forward(d, out)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(10): plan.forward(d, out)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+print("ms/step %.3f  NTT/s %.0f" % (dt * 1e3, batch / dt))
+got = to_host(out[rows]); print("after timing: mismatching rows", int((got != want).any(axis=1).sum()))
+
+from ntt_aie_amd import _lib
+L = _lib.lib()
+print("fused ctl: slots", [L.ntt_plan_info(plan._h, 16 + i) for i in range(8)], "status", L.ntt_plan_info(plan._h, 24),
+      "b_done", L.ntt_plan_info(plan._h, 25), "want", batch * 16, "ok", L.ntt_plan_info(plan._h, 26))
