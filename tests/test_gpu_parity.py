@@ -319,3 +319,57 @@ def test_fused_xcd_local_launch(eng, oracle, monkeypatch):
     # ineligible shapes silently take the two-launch path
     b = _rand(5, n, p, np.uint64, 5)
     assert np.array_equal(eng.to_host(pl.forward(eng.to_device(b, "cuda:0"))), oracle.ntt(b, T, p))
+
+
+def test_graph_capture_and_streams(eng, oracle):
+    """The launch functions do no allocation or synchronisation, so a transform can be captured
+    into a HIP graph and replayed, and runs on whatever stream the caller hands over."""
+    import torch
+
+    p, logn, batch = GOLD, 16, 32
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, 8, 0)
+    T = pl.make_roots(7)
+    pl.set_twiddles(T)
+    a = _rand(batch, n, p, np.uint64, 77)
+    x = eng.to_device(a, "cuda:0")
+    y = torch.zeros_like(x)
+    z = torch.zeros_like(x)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pl.forward(x, y)  # warm-up outside capture, on a side stream
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        pl.forward(x, y)
+        pl.inverse(y, z)
+    y.zero_()
+    z.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(eng.to_host(y[:4]), oracle.ntt(a[:4], T, p, nthreads=4))
+    assert torch.equal(z, x)
+
+
+def test_bench_json_contract():
+    """bench.py prints one JSON line with the fields the driver reads (small batch, no CPU leg)."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--batch", "64", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "NTT/s" and d["dtype"] == "u64"
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
