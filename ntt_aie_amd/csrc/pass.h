@@ -290,6 +290,18 @@ NTT_HD uint32_t elem_eff(const PassArgs<Cfg> &a, int e, bool want) {
     }
 }
 
+// Cache policy of the streamed coefficient traffic (aux bits of the buffer instructions: 2 = nt).
+// Every coefficient is read once and written once per pass, 4 GiB apart: non-temporal on loads,
+// stores and the LDS-DMA measured +1.5-2 % (2.22 -> 2.26 M NTT/s); twiddles stay default-policy.
+#ifndef NTT_AUX_LD
+#define NTT_AUX_LD 2
+#endif
+#ifndef NTT_AUX_ST
+#define NTT_AUX_ST 2
+#endif
+#ifndef NTT_DMA_MOD
+#define NTT_DMA_MOD " nt"
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 // Buffer (SRD) addressing for the direct global accesses: wave-uniform descriptor base
 // (workgroup tile origin of this iteration) + SGPR element offset + one 32-bit lane offset,
@@ -298,10 +310,10 @@ template <class W>
 __device__ __forceinline__ W buf_load(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
     if constexpr (sizeof(W) == 8) {
         using v2 = __attribute__((ext_vector_type(2))) unsigned int;
-        const v2 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+        const v2 d = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, NTT_AUX_LD);
         return ((uint64_t) d.y << 32) | d.x;
     } else {
-        return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+        return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, NTT_AUX_LD);
     }
 }
 template <class W>
@@ -311,9 +323,9 @@ __device__ __forceinline__ void buf_store(W v, __amdgpu_buffer_rsrc_t rs, uint32
         v2 d;
         d.x = (uint32_t) v;
         d.y = (uint32_t) ((uint64_t) v >> 32);
-        __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rs, voff, soff, NTT_AUX_ST);
     } else {
-        __builtin_amdgcn_raw_buffer_store_b32(v, rs, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(v, rs, voff, soff, NTT_AUX_ST);
     }
 }
 #endif
@@ -412,7 +424,7 @@ NTT_HD void phase_linear(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *l
 // LDS[lds_byte (wave-uniform) + 16*l].  M0 carries the LDS base and is restored (hipcc reserves it).
 __device__ __forceinline__ void glds16(const void *gptr, uint32_t lds_byte) {
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" NTT_DMA_MOD "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gptr), "s"(lds_byte)
                  : "memory");

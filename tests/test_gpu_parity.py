@@ -373,3 +373,20 @@ def test_bench_json_contract():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+
+
+@pytest.mark.parametrize("wb,p,g", [(8, GOLD, 7), (4, 3221225473, 5)])
+def test_three_pass_sizes(eng, oracle, wb, p, g):
+    """N = 2^21 and 2^22: three HBM passes (CONTIG + two column passes)."""
+    dt = np.uint32 if wb == 4 else np.uint64
+    for logn in (21, 22):
+        n = 1 << logn
+        T = oracle.make_roots(n, p, g, wb)
+        pl = _plan(eng, logn, p, wb, T)
+        assert pl.hbm_passes == 3
+        a = _rand(2, n, p, dt, logn)
+        f = pl.forward(eng.to_device(a, "cuda:0"))
+        assert np.array_equal(eng.to_host(f), oracle.ntt(a, T, p, nthreads=8))
+        assert np.array_equal(eng.to_host(pl.inverse(f)), a)
+        blk = pl.forward(eng.to_device(a, "cuda:0"), layout=eng.LAYOUT_AIE_BLOCK16)
+        assert np.array_equal(eng.to_host(blk), oracle.block16(oracle.ntt(a, T, p, nthreads=8)))
