@@ -108,6 +108,9 @@ struct PassCfg {
 // Which rounds of a CONTIG pass keep their twiddles in registers across the batch loop.
 // 8-byte words: 30 VGPRs per round; with two rounds resident the kernel drops to 3 waves/SIMD,
 // so only the first executed... (policy tuned on the device)
+#ifndef NTT_CONTIG12_MASK
+#define NTT_CONTIG12_MASK 0x4
+#endif
 #ifndef NTT_CONTIG_GL_MASK2
 #define NTT_CONTIG_GL_MASK2 0x3
 #endif
@@ -125,7 +128,7 @@ constexpr int contig_preload_mask(int log_m, int word_bytes, int log_e = 4) {
     if (rounds <= 1) return 0xF;
     if (rounds == 2) return NTT_CONTIG_GL_MASK2;
     // three rounds: only the outermost one stays resident, and only when it is wave-uniform (SGPRs)
-    return log_m == 12 ? 0x4 : 0x0;
+    return log_m == 12 ? NTT_CONTIG12_MASK : 0x0;
 }
 
 template <class Cfg>
