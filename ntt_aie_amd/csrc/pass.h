@@ -38,6 +38,10 @@
 #include "field.h"
 #include "gl_asm.h"
 
+#ifndef NTT_COL_PREFETCH
+#define NTT_COL_PREFETCH 0  // experiment knob: register prefetch in the 8-stage column pass
+#endif
+
 namespace ntt {
 
 constexpr int LOG_NT = 8;
@@ -101,6 +105,9 @@ struct PassCfg {
     // while the current one is transformed, so no wave ever waits on HBM in steady state.  The
     // DMA writes 1 KiB per wave-instruction linearly, hence these tiles are not padded.
     static constexpr bool DMA = WAVE_LOCAL && !INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8;
+    // column passes of 8-byte words: the NEXT polynomial's 16 words per thread are loaded into a second
+    // register set while the current one is transformed (experiment knob NTT_COL_PREFETCH)
+    static constexpr bool REG_PREFETCH = NTT_COL_PREFETCH && !CONTIG && sizeof(W) == 8 && LOG_M_ == 8;
 
     static NTT_HD uint32_t lds_index(uint32_t lin) { return DMA ? lin : lin + ((lin >> LOG_E) * VW); }
 };
@@ -158,6 +165,7 @@ template <class Cfg>
 struct Ctx {
     using W = typename Cfg::W;
     W x[Cfg::E];
+    W xn[Cfg::REG_PREFETCH ? Cfg::E : 1];  // prefetched words of the next iteration
     W tw[Cfg::R][Cfg::E > 1 ? Cfg::E - 1 : 1];
     uint32_t tid, bx, by;
     uint32_t pg_base;        // first polynomial group of this workgroup (by * ppw for the plain launches)
@@ -333,9 +341,10 @@ __device__ __forceinline__ void buf_store(W v, __amdgpu_buffer_rsrc_t rs, uint32
 }
 #endif
 
-template <class Cfg, int r>
+template <class Cfg, int r, bool NEXT = false>
 NTT_HD void phase_load_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     using W = typename Cfg::W;
+    W *const dstx = NEXT ? c.xn : c.x;
     const W *ubase = a.in + uniform_word<Cfg>(c, a, it);
 #if defined(__HIP_DEVICE_COMPILE__)
     // element offsets stay below 2^32 bytes: (E-1) << (n - LOG_E) words at most
@@ -344,14 +353,14 @@ NTT_HD void phase_load_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
         const uint32_t so = (elem_eff<Cfg>(a, e, Cfg::INV) << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W);
-        c.x[e] = (W) 0;
-        if (c.active) c.x[e] = buf_load<W>(rs, voff, so);
+        dstx[e] = (W) 0;
+        if (c.active) dstx[e] = buf_load<W>(rs, voff, so);
     }
 #else
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
         const size_t eo = (size_t) elem_eff<Cfg>(a, e, Cfg::INV) << (Cfg::win(r) + a.s0);
-        c.x[e] = c.active ? (ubase + eo)[c.lane_ld] : (W) 0;
+        dstx[e] = c.active ? (ubase + eo)[c.lane_ld] : (W) 0;
     }
 #endif
 }
@@ -593,6 +602,9 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     if constexpr (Cfg::DMA) {
         if (group_valid(0)) ex.each([&](C &c) { phase_dma_issue<Cfg>(c, a, ex.lds(), 0); });
     }
+    if constexpr (Cfg::REG_PREFETCH) {
+        if (group_valid(0)) ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, 0); phase_load_direct<Cfg, FIRST, true>(c, a, 0); });
+    }
     int completed = 0;
     for (int it = 0; it < a.ppw; ++it) {
         if (!group_valid(it)) break;
@@ -604,6 +616,12 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             else ex.each([&](C &) { phase_dma_wait<Cfg, false>(); });
             if (group_valid(it + 1)) ex.each([&](C &c) { phase_dma_issue<Cfg>(c, a, ex.lds(), it + 1); });
             ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, tile); });
+        } else if constexpr (Cfg::REG_PREFETCH) {
+            ex.each([&](C &c) {
+#pragma unroll
+                for (int e = 0; e < Cfg::E; ++e) c.x[e] = c.xn[e];
+            });
+            if (group_valid(it + 1)) ex.each([&](C &c) { phase_load_direct<Cfg, FIRST, true>(c, a, it + 1); });
         } else if constexpr (Cfg::DIRECT_LOAD) {
             ex.each([&](C &c) { phase_load_direct<Cfg, FIRST>(c, a, it); });
         } else {
