@@ -136,8 +136,8 @@ int ntt_pointwise_mul(ntt_plan_t plan, const void *d_a, const void *d_b, void *d
                       size_t batch, uint64_t scale, void *stream);
 
 /* Negacyclic product c = a*b mod (x^N + 1, p) with a kind-2 table loaded:
- * unscaled inverse network on a and b -> pointwise product * N^-1 -> forward
- * network.  d_a and d_b are overwritten (used as scratch);
+ * unscaled inverse network on a and b -> forward network of a*b*N^-1, the pointwise
+ * product being folded into the first pass's load.  d_a and d_b are overwritten (used as scratch);
  * d_out may alias d_a. */
 int ntt_polymul_negacyclic(ntt_plan_t plan, void *d_a, void *d_b, void *d_out,
                            size_t batch, void *stream);

@@ -24,6 +24,8 @@ struct ErasedArgs {
     uint64_t scale;  // table form
     uint32_t target_wgs;
     int dbg;  // timing experiments (NTT_DEBUG_FLAGS), 0 in production
+    const void *in2;     // forward CONTIG pass: second operand of a fused pointwise product (or null)
+    uint64_t pw_scale;   // scale * R^2 (see PassArgs::pw_scale)
     const void *skip_if;  // device word: when non-zero the launch is a no-op (fallback behind the fused kernel)
 };
 

@@ -82,10 +82,13 @@ int check_io(const ntt_plan *pl, const void *a, const void *b, size_t batch) {
     return NTT_OK;
 }
 
-int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int layout, hipStream_t s) {
+// in2 != null: transform in[j] * in2[j] * pw_scale (plain) instead of in[j]; the product is folded into
+// the load of the first pass
+int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int layout, hipStream_t s,
+                const void *in2 = nullptr, uint64_t pw_scale_plain = 1) {
     const void *src = d_in;
     const void *skip_if = nullptr;
-    if (pl->d_fused_ctl && d_in != d_out && layout == NTT_LAYOUT_NATURAL && batch >= 64 && batch % 8 == 0 &&
+    if (pl->d_fused_ctl && !in2 && d_in != d_out && layout == NTT_LAYOUT_NATURAL && batch >= 64 && batch % 8 == 0 &&
         batch <= pl->fused_max_batch) {
         // one persistent XCD-local launch; the ordinary passes below then only run (device-side
         // decision, no host sync) if its check kernel did not certify the result
@@ -97,6 +100,10 @@ int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
     for (const PassDesc &pd : pl->passes) {
         ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
         a.skip_if = skip_if;
+        if (&pd == &pl->passes.front() && in2) {  // first pass only (d_out may alias d_in)
+            a.in2 = in2;
+            a.pw_scale = to_table_form(to_table_form(pw_scale_plain % pl->p, pl->p, pl->word_bytes), pl->p, pl->word_bytes);
+        }
         a.tw = pl->d_tw_fwd;
         a.layout = layout;
         hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_fwd(pd.contig, pd.log_m, a, s)
@@ -440,13 +447,8 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
     if (rc) return rc;
     rc = run_inverse(pl, d_b, d_b, batch, NTT_LAYOUT_NATURAL, 0, s);
     if (rc) return rc;
-    const size_t count = batch << pl->logn;
-    hipError_t e = pl->word_bytes == 8
-                       ? ntt::launch_pointwise_gl(d_a, d_b, d_out, count, pl->ninv_plain, s)
-                       : ntt::launch_pointwise_m32(d_a, d_b, d_out, count, (uint32_t) pl->p, pl->pinv,
-                                                   pl->r2, (uint32_t) pl->ninv_plain, s);
-    if (e != hipSuccess) return (int) e;
-    return run_forward(pl, d_out, d_out, batch, NTT_LAYOUT_NATURAL, s);
+    // pointwise product * N^-1 folded into the first pass of the final forward transform
+    return run_forward(pl, d_a, d_out, batch, NTT_LAYOUT_NATURAL, s, d_b, pl->ninv_plain);
 }
 
 int ntt_forward_stages(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int stage, void *stream) {

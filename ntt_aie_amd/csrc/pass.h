@@ -124,8 +124,9 @@ struct PassCfg {
 // Radix of the register rounds of a CONTIG pass.  Goldilocks passes of 7-8 stages that are not
 // the last pass of the plan run radix-8 rounds (3+3+2 stages): 16 data + 34 twiddle registers
 // instead of 32 + 60, so ~5 waves per SIMD hide the HBM latency that 3 waves could not.
-constexpr int contig_log_e(int log_m, int word_bytes, bool last_pass) {
-    return (word_bytes == 8 && !last_pass && (log_m == 7 || log_m == 8)) ? 3 : 4;
+constexpr int contig_log_e(int log_m, int word_bytes, bool last_pass, bool fused_product = false) {
+    // (the LDS-DMA kernel has no place to multiply: a fused pointwise product takes the radix-16 kernel)
+    return (word_bytes == 8 && !last_pass && !fused_product && (log_m == 7 || log_m == 8)) ? 3 : 4;
 }
 
 constexpr int contig_preload_mask(int log_m, int word_bytes, int log_e = 4) {
@@ -154,6 +155,8 @@ struct PassArgs {
     int log_up;
     int layout;    // transform-domain layout; honoured by the pass holding the top stage
     int do_scale;  // inverse: multiply by `scale` (N^-1, table form) after the last round
+    const W *in2;            // non-null (forward CONTIG pass only): load in[j] * in2[j] * pw_scale instead of in[j]
+    W pw_scale;              // scale * R^2 in table form's domain: mul(mul(x, y), pw_scale) == x * y * scale
     int pg_stride;           // polynomial-group step per iteration (1 for the plain launches)
     const uint32_t *skip_if; // non-null: every workgroup returns at once when *skip_if != 0 (guarded fallback)
     int dbg;       // timing experiments only: 1 = every iteration re-reads polynomial group 0,
@@ -356,11 +359,22 @@ NTT_HD void phase_load_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
         dstx[e] = (W) 0;
         if (c.active) dstx[e] = buf_load<W>(rs, voff, so);
     }
+    if (Cfg::CONTIG && !Cfg::INV && a.in2 != nullptr) {
+        const __amdgpu_buffer_rsrc_t rs2 =
+            __builtin_amdgcn_make_buffer_rsrc((void *) (a.in2 + uniform_word<Cfg>(c, a, it)), 0, -1, 0x00020000);
+#pragma unroll
+        for (int e = 0; e < Cfg::E; ++e) {
+            const uint32_t so = ((uint32_t) e << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W);
+            if (c.active) dstx[e] = a.field.mul(a.field.mul(dstx[e], buf_load<W>(rs2, voff, so)), a.pw_scale);
+        }
+    }
 #else
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
         const size_t eo = (size_t) elem_eff<Cfg>(a, e, Cfg::INV) << (Cfg::win(r) + a.s0);
         dstx[e] = c.active ? (ubase + eo)[c.lane_ld] : (W) 0;
+        if (Cfg::CONTIG && !Cfg::INV && a.in2 != nullptr && c.active)
+            dstx[e] = a.field.mul(a.field.mul(dstx[e], (a.in2 + uniform_word<Cfg>(c, a, it) + eo)[c.lane_ld]), a.pw_scale);
     }
 #endif
 }
@@ -419,6 +433,11 @@ NTT_HD void phase_linear(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *l
             Ch v;
             if (active) {
                 v = *reinterpret_cast<const Ch *>(a.in + tile0 + lin);
+                if (a.in2 != nullptr) {  // fused pointwise product (negacyclic polymul's middle leg)
+                    const Ch w = *reinterpret_cast<const Ch *>(a.in2 + tile0 + lin);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) v.v[k] = a.field.mul(a.field.mul(v.v[k], w.v[k]), a.pw_scale);
+                }
             } else {
 #pragma unroll
                 for (int k = 0; k < V; ++k) v.v[k] = 0;

@@ -57,6 +57,8 @@ struct Erased {
     int layout, do_scale;
     uint64_t scale;
     uint32_t target_wgs;
+    const void *in2;
+    uint64_t pw_scale;
 };
 
 template <class F>
@@ -86,6 +88,8 @@ int run_cfg(const Erased &e) {
     a.scale = (W) e.scale;
     a.dbg = 0;
     a.pg_stride = 1;
+    a.in2 = (const W *) e.in2;
+    a.pw_scale = (W) e.pw_scale;
     a.skip_if = nullptr;
     PassGeom g = pass_geometry(e.n, e.s0, Cfg::LOG_M, Cfg::LOG_C, Cfg::LOG_U, Cfg::CONTIG, e.batch, e.target_wgs);
     a.ppw = g.ppw;
@@ -121,7 +125,7 @@ int dispatch(bool contig, int log_m, const Erased &e) {
     case M:         \
         return run_cfg<PassCfg<F, M, LOG_COLS, false, INV, 0xF>>(e);
     if (contig) {
-        if (contig_log_e(log_m, sizeof(typename F::W), e.s0 + log_m == e.n) == 3) {
+        if (contig_log_e(log_m, sizeof(typename F::W), e.s0 + log_m == e.n, e.in2 != nullptr) == 3) {
             if (log_m == 7) return run_cfg<PassCfg<F, 7, 0, true, INV, 0xF, 3>>(e);
             return run_cfg<PassCfg<F, 8, 0, true, INV, 0xF, 3>>(e);
         }
@@ -208,6 +212,44 @@ int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, con
         else
             rc = inverse ? dispatch<FieldM32, true>(passes[i].contig, passes[i].log_m, e)
                          : dispatch<FieldM32, false>(passes[i].contig, passes[i].log_m, e);
+        if (rc) return rc;
+        cur = out;
+    }
+    return 0;
+}
+
+// forward transform of (in * in2 * scale): the fused-product first pass (polymul's last leg)
+int emu_forward_product(int word_bytes, int logn, uint64_t p, const void *T_plain, const void *in, const void *in2,
+                        void *out, uint32_t batch, uint64_t scale, uint32_t target_wgs) {
+    const size_t N = (size_t) 1 << logn;
+    std::vector<uint32_t> t32(N);
+    std::vector<uint64_t> t64(N);
+    for (size_t i = 0; i < N; i++) {
+        const uint64_t t = word_bytes == 4 ? ((const uint32_t *) T_plain)[i] : ((const uint64_t *) T_plain)[i];
+        t32[i] = (uint32_t) to_table_form(t, p, 4 == word_bytes ? 4 : 8);
+        t64[i] = to_table_form(t, p, 8);
+    }
+    Erased e;
+    memset(&e, 0, sizeof(e));
+    e.p = (uint32_t) p;
+    if (word_bytes == 4) {
+        e.pinv = mont_pinv((uint32_t) p);
+        e.r2 = mont_r2((uint32_t) p);
+    }
+    e.n = logn;
+    e.batch = batch;
+    e.target_wgs = target_wgs;
+    e.tw = word_bytes == 4 ? (const void *) t32.data() : (const void *) t64.data();
+    const std::vector<PassDesc> passes = plan_passes(logn);
+    const void *cur = in;
+    for (size_t i = 0; i < passes.size(); i++) {
+        e.in = cur;
+        e.out = out;
+        e.s0 = passes[i].s0;
+        e.in2 = i == 0 ? in2 : nullptr;
+        e.pw_scale = to_table_form(to_table_form(scale % p, p, word_bytes), p, word_bytes);
+        const int rc = word_bytes == 8 ? dispatch<FieldGL, false>(passes[i].contig, passes[i].log_m, e)
+                                       : dispatch<FieldM32, false>(passes[i].contig, passes[i].log_m, e);
         if (rc) return rc;
         cur = out;
     }

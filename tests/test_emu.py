@@ -96,3 +96,21 @@ def test_field_arithmetic_edges():
                 assert L.emu_m32_mul_plain(a, b, q) == a * b % q
                 assert L.emu_m32_add(a, b, q) == (a + b) % q
                 assert L.emu_m32_sub(a, b, q) == (a - b) % q
+
+
+def test_fused_pointwise_first_pass(oracle):
+    """forward(in * in2 * scale) with the product folded into the first pass's load."""
+    for wb, p, g in FIELDS[:2]:
+        dt = np.uint32 if wb == 4 else np.uint64
+        for logn in (2, 4, 6, 10, 13):
+            n = 1 << logn
+            T = oracle.make_roots(n, p, g, wb)
+            rng = np.random.default_rng(logn)
+            a = (rng.integers(0, 2**63, size=(3, n), dtype=np.uint64) % np.uint64(p)).astype(dt)
+            b = (rng.integers(0, 2**63, size=(3, n), dtype=np.uint64) % np.uint64(p)).astype(dt)
+            out = np.zeros_like(a)
+            scale = 12345 % p
+            rc = emu_lib.lib().emu_forward_product(wb, logn, p, T.ctypes.data, a.ctypes.data, b.ctypes.data,
+                                                   out.ctypes.data, 3, scale, 8)
+            assert rc == 0
+            assert np.array_equal(out, oracle.ntt(oracle.pointwise(a, b, p, scale), T, p)), (wb, logn)
