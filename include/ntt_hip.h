@@ -142,6 +142,11 @@ int ntt_pointwise_mul(ntt_plan_t plan, const void *d_a, const void *d_b, void *d
 int ntt_polymul_negacyclic(ntt_plan_t plan, void *d_a, void *d_b, void *d_out,
                            size_t batch, void *stream);
 
+/* Precondition check (blocking, diagnostic): how many of the batch*N words are >= p.  The transforms
+ * assume canonical residues, as the reference's vector_modadd / vector_modsub do (src/aie_core.cc:41-62);
+ * a non-canonical word gives an unspecified (but memory-safe) result. */
+int ntt_count_noncanonical(ntt_plan_t plan, const void *d_buf, size_t batch, uint64_t *host_count);
+
 /* Reference-style partial network (test_stage hook, src/test.cpp:55-58, 67):
  * run stages 0..stage only.  Slow path (one launch per stage), for bring-up. */
 int ntt_forward_stages(ntt_plan_t plan, const void *d_in, void *d_out, size_t batch,

@@ -29,7 +29,7 @@ LAYOUT_AIE_BLOCK16 = 1
 EXPORTS = (
     "ntt_version", "ntt_error_string", "ntt_device_count", "ntt_plan_create", "ntt_plan_destroy",
     "ntt_plan_set_twiddles", "ntt_make_roots", "ntt_make_table", "ntt_plan_generate_twiddles", "ntt_plan_get_twiddles", "ntt_plan_info", "ntt_forward",
-    "ntt_forward_profile", "ntt_inverse", "ntt_pointwise_mul", "ntt_polymul_negacyclic", "ntt_forward_stages",
+    "ntt_forward_profile", "ntt_inverse", "ntt_pointwise_mul", "ntt_polymul_negacyclic", "ntt_count_noncanonical", "ntt_forward_stages",
 )
 
 
@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
         L.ntt_inverse.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, vp]
         L.ntt_pointwise_mul.argtypes = [vp, vp, vp, vp, sz, u64, vp]
         L.ntt_polymul_negacyclic.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.ntt_count_noncanonical.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64)]
         L.ntt_forward_stages.argtypes = [vp, vp, vp, sz, C.c_int, vp]
         _lib = L
     return _lib

@@ -54,6 +54,9 @@ hipError_t launch_gen_table_gl(void *T, int logn, int kind, uint64_t base_m, uin
 hipError_t launch_gen_table_m32(void *T, int logn, int kind, uint32_t base_m, uint32_t one_m, uint32_t p,
                                 uint32_t pinv, uint32_t r2, hipStream_t s);
 
+// number of words >= p in a buffer (precondition check); d_out = one zeroed 64-bit device word
+hipError_t launch_count_noncanonical(const void *a, size_t count, int word_bytes, uint64_t p, void *d_out, hipStream_t s);
+
 // one stage of the network, one thread per butterfly (bring-up path, test_stage hook)
 hipError_t launch_stage_gl(void *data, const void *tw, int n, int stage, size_t batch, hipStream_t s);
 hipError_t launch_stage_m32(void *data, const void *tw, int n, int stage, size_t batch, uint32_t p,

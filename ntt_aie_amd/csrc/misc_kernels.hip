@@ -100,6 +100,17 @@ __global__ __launch_bounds__(256) void gen_table_kernel(typename F::W *T, int lo
     }
 }
 
+// precondition check: number of words >= p (the kernels, like the reference's vector_modadd /
+// vector_modsub, src/aie_core.cc:41-62, assume canonical residues)
+template <class W>
+__global__ __launch_bounds__(256) void count_noncanonical_kernel(const W *a, size_t count, W p, unsigned long long *out) {
+    unsigned long long bad = 0;
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) bad += a[i] >= p;
+    for (int off = 32; off; off >>= 1) bad += __shfl_down(bad, off, 64);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd(out, bad);
+}
+
 inline unsigned grid_for(size_t work) {
     size_t g = (work + 255) / 256;
     if (g > 8192) g = 8192;  // 256 CUs x 8 x 4: grid-stride the rest
@@ -137,6 +148,16 @@ hipError_t launch_gen_table_m32(void *T, int logn, int kind, uint32_t base_m, ui
                                 uint32_t pinv, uint32_t r2, hipStream_t s) {
     hipLaunchKernelGGL(gen_table_kernel<FieldM32>, dim3(grid_for((size_t) 1 << logn)), dim3(256), 0, s,
                        (uint32_t *) T, logn, kind, base_m, one_m, FieldM32{p, pinv, r2});
+    return hipGetLastError();
+}
+
+hipError_t launch_count_noncanonical(const void *a, size_t count, int word_bytes, uint64_t p, void *d_out, hipStream_t s) {
+    if (word_bytes == 8)
+        hipLaunchKernelGGL(count_noncanonical_kernel<uint64_t>, dim3(grid_for(count)), dim3(256), 0, s,
+                           (const uint64_t *) a, count, p, (unsigned long long *) d_out);
+    else
+        hipLaunchKernelGGL(count_noncanonical_kernel<uint32_t>, dim3(grid_for(count)), dim3(256), 0, s,
+                           (const uint32_t *) a, count, (uint32_t) p, (unsigned long long *) d_out);
     return hipGetLastError();
 }
 

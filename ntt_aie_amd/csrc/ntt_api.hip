@@ -451,6 +451,25 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
     return run_forward(pl, d_a, d_out, batch, NTT_LAYOUT_NATURAL, s, d_b, pl->ninv_plain);
 }
 
+int ntt_count_noncanonical(ntt_plan_t pl, const void *d_buf, size_t batch, uint64_t *host_count) {
+    if (!pl || !host_count) return NTT_E_ARG;
+    *host_count = 0;
+    if (batch == 0) return NTT_OK;
+    if (!d_buf) return NTT_E_ARG;
+    DeviceGuard g(pl->device);
+    if (g.err != hipSuccess) return (int) g.err;
+    unsigned long long *d_cnt = nullptr;
+    hipError_t e = hipMalloc(&d_cnt, sizeof(*d_cnt));
+    if (e != hipSuccess) return (int) e;
+    e = hipMemset(d_cnt, 0, sizeof(*d_cnt));
+    if (e == hipSuccess) e = ntt::launch_count_noncanonical(d_buf, batch << pl->logn, pl->word_bytes, pl->p, d_cnt, nullptr);
+    unsigned long long h = 0;
+    if (e == hipSuccess) e = hipMemcpy(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost);
+    (void) hipFree(d_cnt);
+    *host_count = h;
+    return (int) e;
+}
+
 int ntt_forward_stages(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int stage, void *stream) {
     int rc = check_io(pl, d_in, d_out, batch);
     if (rc) return rc;

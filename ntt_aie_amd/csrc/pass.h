@@ -121,12 +121,12 @@ struct PassCfg {
 #ifndef NTT_CONTIG_GL_MASK2
 #define NTT_CONTIG_GL_MASK2 0x3
 #endif
-// Radix of the register rounds of a CONTIG pass.  Goldilocks passes of 7-8 stages that are not
-// the last pass of the plan run radix-8 rounds (3+3+2 stages): 16 data + 34 twiddle registers
+// Radix of the register rounds of a CONTIG pass.  Goldilocks passes of 7-9 stages that are not
+// the last pass of the plan run radix-8 rounds (3+3+2 or 3+3+3 stages; a unit is at most one wave): 16 data + 34 twiddle registers
 // instead of 32 + 60, so ~5 waves per SIMD hide the HBM latency that 3 waves could not.
 constexpr int contig_log_e(int log_m, int word_bytes, bool last_pass, bool fused_product = false) {
     // (the LDS-DMA kernel has no place to multiply: a fused pointwise product takes the radix-16 kernel)
-    return (word_bytes == 8 && !last_pass && !fused_product && (log_m == 7 || log_m == 8)) ? 3 : 4;
+    return (word_bytes == 8 && !last_pass && !fused_product && log_m >= 7 && log_m <= 9) ? 3 : 4;
 }
 
 constexpr int contig_preload_mask(int log_m, int word_bytes, int log_e = 4) {

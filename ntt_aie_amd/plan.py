@@ -169,6 +169,13 @@ class NTTPlan:
                                                 self._stream(stream)), "ntt_polymul_negacyclic")
         return out
 
+    def count_noncanonical(self, buf: torch.Tensor) -> int:
+        """How many words of `buf` are >= p (the transforms require canonical residues)."""
+        b = self._batch(buf)
+        n = C.c_uint64(0)
+        check(_lib.lib().ntt_count_noncanonical(self._h, buf.data_ptr(), b, C.byref(n)), "ntt_count_noncanonical")
+        return int(n.value)
+
     def forward_stages(self, inp: torch.Tensor, stage: int, out: torch.Tensor | None = None,
                        stream=None) -> torch.Tensor:
         """Stages 0..stage only (the reference's test_stage hook, src/test.cpp:55-58, 67)."""

@@ -127,7 +127,8 @@ int dispatch(bool contig, int log_m, const Erased &e) {
     if (contig) {
         if (contig_log_e(log_m, sizeof(typename F::W), e.s0 + log_m == e.n, e.in2 != nullptr) == 3) {
             if (log_m == 7) return run_cfg<PassCfg<F, 7, 0, true, INV, 0xF, 3>>(e);
-            return run_cfg<PassCfg<F, 8, 0, true, INV, 0xF, 3>>(e);
+            if (log_m == 8) return run_cfg<PassCfg<F, 8, 0, true, INV, 0xF, 3>>(e);
+            return run_cfg<PassCfg<F, 9, 0, true, INV, 0xF, 3>>(e);
         }
         switch (log_m) {
             CASE_CONTIG(1) CASE_CONTIG(2) CASE_CONTIG(3) CASE_CONTIG(4) CASE_CONTIG(5) CASE_CONTIG(6)

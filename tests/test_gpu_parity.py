@@ -393,3 +393,15 @@ def test_three_pass_sizes(eng, oracle, wb, p, g):
         assert np.array_equal(eng.to_host(pl.inverse(f)), a)
         blk = pl.forward(eng.to_device(a, "cuda:0"), layout=eng.LAYOUT_AIE_BLOCK16)
         assert np.array_equal(eng.to_host(blk), oracle.block16(oracle.ntt(a, T, p, nthreads=8)))
+
+
+def test_count_noncanonical(eng):
+    for wb, p in [(8, GOLD), (4, 3329)]:
+        dt = np.uint32 if wb == 4 else np.uint64
+        pl = eng.NTTPlan(10, p, wb, 0)
+        a = _rand(7, 1024, p, dt, 3)
+        assert pl.count_noncanonical(eng.to_device(a, "cuda:0")) == 0
+        a[0, 0] = p
+        a[3, 77] = np.iinfo(dt).max
+        a[6, 1023] = p + 1 if wb == 4 else p + 5
+        assert pl.count_noncanonical(eng.to_device(a, "cuda:0")) == 3
