@@ -385,8 +385,28 @@ NTT_HD void phase_store_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     W *ubase = a.out + uniform_word<Cfg>(c, a, it, 4);
     if (!c.active || (a.dbg & 2)) return;
 #if defined(__HIP_DEVICE_COMPILE__)
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) ubase, 0, -1, 0x00020000);
     const uint32_t voff = c.lane_st * (uint32_t) sizeof(W);
+    if constexpr (Cfg::DMA) {
+        // The LDS-DMA wait of the next iteration counts on EXACTLY E store instructions being
+        // younger than the prefetch (phase_dma_wait): issue them by hand so that no compiler
+        // decision (merging, splitting) can change that number.  Raw SRD: base, stride 0,
+        // 2^32-1 records, the same flags make_buffer_rsrc uses.
+        using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
+        const uint64_t base = (uint64_t) (uintptr_t) ubase;
+        u32x4 srd;
+        srd.x = __builtin_amdgcn_readfirstlane((uint32_t) base);
+        srd.y = __builtin_amdgcn_readfirstlane((uint32_t) (base >> 32) & 0xFFFFu);
+        srd.z = 0xFFFFFFFFu;
+        srd.w = 0x00020000u;
+        asm volatile("s_nop 4" ::: "memory");  // v_readfirstlane -> VMEM descriptor read
+#pragma unroll
+        for (int e = 0; e < Cfg::E; ++e) {
+            const uint32_t so = __builtin_amdgcn_readfirstlane(((uint32_t) e << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W));
+            asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen nt" ::"v"(c.x[e]), "v"(voff), "s"(srd), "s"(so) : "memory");
+        }
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) ubase, 0, -1, 0x00020000);
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
         const uint32_t so = (elem_eff<Cfg>(a, e, !Cfg::INV) << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W);
