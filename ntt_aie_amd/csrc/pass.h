@@ -45,7 +45,7 @@
 namespace ntt {
 
 constexpr int LOG_NT = 8;
-constexpr int NT = 1 << LOG_NT;  // threads per workgroup = 4 waves of 64
+constexpr int NT = 1 << LOG_NT;  // default threads per workgroup = 4 waves of 64 (PassCfg::NT is per kernel)
 
 enum { LAYOUT_NATURAL = 0, LAYOUT_AIE_BLOCK16 = 1 };
 
@@ -61,7 +61,8 @@ NTT_HD void static_for(Fn &&f) {
     }
 }
 
-template <class F_, int LOG_M_, int LOG_C_, bool CONTIG_, bool INV_, int PRELOAD_MASK_ = 0xF, int LOG_E_ = 4>
+template <class F_, int LOG_M_, int LOG_C_, bool CONTIG_, bool INV_, int PRELOAD_MASK_ = 0xF, int LOG_E_ = 4,
+          int LOG_NT_ = LOG_NT>
 struct PassCfg {
     using F = F_;
     using W = typename F::W;
@@ -78,8 +79,10 @@ struct PassCfg {
     static constexpr int M = 1 << LOG_M;
     static constexpr int C = 1 << LOG_C;
     static constexpr int LOG_Q = LOG_M - LOG_E;  // threads along mid
-    static constexpr int LOG_U = LOG_NT + LOG_E - LOG_M - LOG_C;  // units per workgroup
-    static_assert(LOG_U >= 0, "tile does not fit a 256-thread workgroup");
+    static constexpr int LOG_NT = LOG_NT_;  // log2 threads per workgroup (8, or 9 for the wide radix-8 passes)
+    static constexpr int NT = 1 << LOG_NT_;
+    static constexpr int LOG_U = LOG_NT_ + LOG_E - LOG_M - LOG_C;  // units per workgroup
+    static_assert(LOG_U >= 0, "tile does not fit the workgroup");
     static_assert(!CONTIG || LOG_C == 0, "contiguous pass has no column dimension");
     static constexpr int R = (LOG_M + LOG_E - 1) / LOG_E;  // register rounds
     static constexpr int VW = 16 / (int) sizeof(W);        // words per 16-byte chunk
@@ -126,7 +129,13 @@ struct PassCfg {
 // instead of 32 + 60, so ~5 waves per SIMD hide the HBM latency that 3 waves could not.
 constexpr int contig_log_e(int log_m, int word_bytes, bool last_pass, bool fused_product = false) {
     // (the LDS-DMA kernel has no place to multiply: a fused pointwise product takes the radix-16 kernel)
-    return (word_bytes == 8 && !last_pass && !fused_product && log_m >= 7 && log_m <= 9) ? 3 : 4;
+    return (word_bytes == 8 && !last_pass && !fused_product && log_m >= 7) ? 3 : 4;
+}
+// ... and 10-12 stages run radix-8 too, in 512-thread workgroups (a unit of 1024-4096 words spans 2-8
+// waves): all 28 twiddles of the four rounds stay in registers, where the radix-16 kernel had to reload 30-45
+// of them from L2 for every polynomial.
+constexpr int contig_log_nt(int log_m, int word_bytes, bool last_pass, bool fused_product = false) {
+    return (contig_log_e(log_m, word_bytes, last_pass, fused_product) == 3 && log_m >= 10) ? 9 : 8;
 }
 
 constexpr int contig_preload_mask(int log_m, int word_bytes, int log_e = 4) {

@@ -26,16 +26,16 @@ struct EmuExec {
     std::vector<Ctx<Cfg>> ctx;
     std::vector<typename Cfg::W> tile;
     uint32_t bx, by;
-    EmuExec() : ctx(NT), tile(Cfg::DMA ? 2 * Cfg::TILE_WORDS : Cfg::LDS_WORDS) {}
+    EmuExec() : ctx(Cfg::NT), tile(Cfg::DMA ? 2 * Cfg::TILE_WORDS : Cfg::LDS_WORDS) {}
     void init(const PassArgs<Cfg> &a) {
-        for (int t = 0; t < NT; t++) phase_init<Cfg>(ctx[t], a, (uint32_t) t, bx, by);
+        for (int t = 0; t < Cfg::NT; t++) phase_init<Cfg>(ctx[t], a, (uint32_t) t, bx, by);
     }
     // only_wave >= 0: step just that wave's 64 lanes (used to prove WAVE_LOCAL passes never read
     // another wave's LDS words: the four waves are then run one after the other, start to finish)
     int only_wave = -1;
     template <class Fn>
     void each(Fn &&f) {
-        const int lo = only_wave < 0 ? 0 : 64 * only_wave, hi = only_wave < 0 ? NT : lo + 64;
+        const int lo = only_wave < 0 ? 0 : 64 * only_wave, hi = only_wave < 0 ? Cfg::NT : lo + 64;
         for (int t = lo; t < hi; t++) f(ctx[t]);
     }
     template <class B>
@@ -104,7 +104,7 @@ int run_cfg(const Erased &e) {
             // poison the tile: a read of a word nobody wrote this launch shows up as garbage
             memset(ex.tile.data(), 0xA5, ex.tile.size() * sizeof(W));
             if constexpr (Cfg::WAVE_LOCAL) {
-                for (int w = 0; w < NT / 64; w++) {
+                for (int w = 0; w < Cfg::NT / 64; w++) {
                     ex.only_wave = w;
                     run_pass<Cfg>(ex, a);
                     memset(ex.tile.data(), 0x5A, ex.tile.size() * sizeof(W));  // nothing may survive
@@ -128,7 +128,10 @@ int dispatch(bool contig, int log_m, const Erased &e) {
         if (contig_log_e(log_m, sizeof(typename F::W), e.s0 + log_m == e.n, e.in2 != nullptr) == 3) {
             if (log_m == 7) return run_cfg<PassCfg<F, 7, 0, true, INV, 0xF, 3>>(e);
             if (log_m == 8) return run_cfg<PassCfg<F, 8, 0, true, INV, 0xF, 3>>(e);
-            return run_cfg<PassCfg<F, 9, 0, true, INV, 0xF, 3>>(e);
+            if (log_m == 9) return run_cfg<PassCfg<F, 9, 0, true, INV, 0xF, 3>>(e);
+            if (log_m == 10) return run_cfg<PassCfg<F, 10, 0, true, INV, 0xF, 3, 9>>(e);
+            if (log_m == 11) return run_cfg<PassCfg<F, 11, 0, true, INV, 0xF, 3, 9>>(e);
+            return run_cfg<PassCfg<F, 12, 0, true, INV, 0xF, 3, 9>>(e);
         }
         switch (log_m) {
             CASE_CONTIG(1) CASE_CONTIG(2) CASE_CONTIG(3) CASE_CONTIG(4) CASE_CONTIG(5) CASE_CONTIG(6)

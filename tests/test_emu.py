@@ -54,7 +54,8 @@ def test_multi_pass_planner_splits(oracle, wb, p, g):
             _run(oracle, wb, logn, p, g, 3, inverse=inv, layout=1, tw=8, seed=logn, inplace=True)
 
 
-@pytest.mark.parametrize("ov", [(8, 4), (8, 5), (7, 6), (8, 7), (8, 8), (12, 4), (5, 4), (4, 6), (5, 5, 8)])
+@pytest.mark.parametrize("ov", [(8, 4), (8, 5), (7, 6), (8, 7), (8, 8), (9, 4), (10, 4), (11, 5), (12, 4), (5, 4), (4, 6),
+                                (5, 5, 8)])
 def test_every_tile_shape(oracle, ov):
     logn = sum(ov)
     for wb, p, g in FIELDS[:2]:
