@@ -405,3 +405,21 @@ def test_count_noncanonical(eng):
         a[3, 77] = np.iinfo(dt).max
         a[6, 1023] = p + 1 if wb == 4 else p + 5
         assert pl.count_noncanonical(eng.to_device(a, "cuda:0")) == 3
+
+
+def test_cxx_host_through_c_abi(tmp_path):
+    """A C++ host (tests/cxx/ref_host.cpp, the shape of INTEGRATION.md section 1) linked against
+    libntt_hip.so runs the reference's test case and verifies it the reference's way."""
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = str(tmp_path / "ref_host")
+    lib, orc = os.path.join(ROOT, "ntt_aie_amd"), os.path.join(ROOT, "oracle")
+    subprocess.check_call(["make", "-C", orc, "libntt_oracle.so"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["hipcc", "-O2", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "cxx", "ref_host.cpp"),
+                           "-I" + os.path.join(ROOT, "include"), "-I" + orc, "-L" + lib, "-lntt_hip", "-L" + orc,
+                           "-lntt_oracle", "-Wl,-rpath," + lib, "-Wl,-rpath," + orc, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "PASS!" in out.stdout and len([l for l in out.stdout.splitlines() if l.strip().isdigit()]) == 10
