@@ -200,6 +200,22 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     pl->fused_max_batch = 0;
     if (const char *e = getenv("NTT_FUSED")) pl->fused = atoi(e);
     pl->passes = plan_passes(logn);
+    if (const char *e = getenv("NTT_PLAN_SPLIT")) {  // experiment knob: "8,6,6" = CONTIG 8 stages + two 6-stage column passes
+        std::vector<PassDesc> v;
+        int s0 = 0;
+        bool ok = true;
+        for (const char *c = e; *c && ok;) {
+            char *end = nullptr;
+            const long m = strtol(c, &end, 10);
+            if (end == c) break;
+            if (v.empty()) ok = m >= 1 && m <= MAX_CONTIG_LOG_M;
+            else ok = m >= MIN_COL_LOG_M && m <= MAX_COL_LOG_M;
+            v.push_back({v.empty(), s0, (int) m});
+            s0 += (int) m;
+            c = *end == ',' ? end + 1 : end;
+        }
+        if (ok && s0 == logn && !v.empty()) pl->passes = v;  // anything else: keep the default split
+    }
     DeviceGuard g(device);
     if (g.err != hipSuccess) {
         delete pl;
