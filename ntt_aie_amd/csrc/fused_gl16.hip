@@ -47,7 +47,7 @@ struct FusedCtl {  // device words, zeroed by hipMemsetAsync before every launch
 };
 
 using CfgA = PassCfg<FieldGL, 8, 0, true, false, 0xF, 3>;
-using CfgB = PassCfg<FieldGL, 8, LOG_COLS, false, false, 0xF>;
+using CfgB = ColPassCfg<FieldGL, 8, false>;
 constexpr int TILE_LDS_WORDS = 2 * CfgA::TILE_WORDS > CfgB::LDS_WORDS ? 2 * CfgA::TILE_WORDS : CfgB::LDS_WORDS;
 
 template <class Cfg, bool PRODUCER>

@@ -8,10 +8,6 @@
 
 namespace ntt {
 
-// Column tile width: 2^LOG_COLS consecutive words per row segment (128 B for
-// 8-byte words, 64 B for 4-byte words).
-constexpr int LOG_COLS = 4;
-
 struct ErasedArgs {
     const void *in;
     void *out;

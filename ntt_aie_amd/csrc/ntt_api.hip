@@ -214,6 +214,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
             s0 += (int) m;
             c = *end == ',' ? end + 1 : end;
         }
+        if (v.size() > 1 && v[0].log_m < ntt::col_log_c(word_bytes)) ok = false;  // column tiles are 2^log_c words wide
         if (ok && s0 == logn && !v.empty()) pl->passes = v;  // anything else: keep the default split
     }
     DeviceGuard g(device);

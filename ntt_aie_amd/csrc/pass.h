@@ -138,6 +138,12 @@ constexpr int contig_log_nt(int log_m, int word_bytes, bool last_pass, bool fuse
     return (contig_log_e(log_m, word_bytes, last_pass, fused_product) == 3 && log_m >= 10) ? 9 : 8;
 }
 
+// Column tile: 2^LOG_C consecutive words per row segment = one 128-byte line either way:
+// 16 columns of 8-byte words in 256-thread workgroups, 32 columns of 4-byte words in 512-thread ones
+// (with 16 columns the 4-byte passes moved 64-byte half lines: 3.9 ms against 1.8 ms per 4 GiB).
+constexpr int col_log_c(int word_bytes) { return word_bytes == 8 ? 4 : 5; }
+constexpr int col_log_nt(int word_bytes) { return word_bytes == 8 ? 8 : 9; }
+
 constexpr int contig_preload_mask(int log_m, int word_bytes, int log_e = 4) {
     if (log_e < 4) return 0xF;
     const int rounds = (log_m + 3) / 4;
@@ -147,6 +153,9 @@ constexpr int contig_preload_mask(int log_m, int word_bytes, int log_e = 4) {
     // three rounds: only the outermost one stays resident, and only when it is wave-uniform (SGPRs)
     return log_m == 12 ? NTT_CONTIG12_MASK : 0x0;
 }
+
+template <class F, int LOG_M, bool INV>
+using ColPassCfg = PassCfg<F, LOG_M, col_log_c(sizeof(typename F::W)), false, INV, 0xF, 4, col_log_nt(sizeof(typename F::W))>;
 
 template <class Cfg>
 struct PassArgs {

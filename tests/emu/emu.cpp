@@ -19,8 +19,6 @@ using namespace ntt::host;
 
 namespace {
 
-constexpr int LOG_COLS = 4;  // keep equal to kernels.h
-
 template <class Cfg>
 struct EmuExec {
     std::vector<Ctx<Cfg>> ctx;
@@ -123,7 +121,7 @@ int dispatch(bool contig, int log_m, const Erased &e) {
         return run_cfg<PassCfg<F, M, 0, true, INV, contig_preload_mask(M, sizeof(typename F::W))>>(e);
 #define CASE_COL(M) \
     case M:         \
-        return run_cfg<PassCfg<F, M, LOG_COLS, false, INV, 0xF>>(e);
+        return run_cfg<ColPassCfg<F, M, INV>>(e);
     if (contig) {
         if (contig_log_e(log_m, sizeof(typename F::W), e.s0 + log_m == e.n, e.in2 != nullptr) == 3) {
             if (log_m == 7) return run_cfg<PassCfg<F, 7, 0, true, INV, 0xF, 3>>(e);

@@ -54,11 +54,13 @@ def test_multi_pass_planner_splits(oracle, wb, p, g):
             _run(oracle, wb, logn, p, g, 3, inverse=inv, layout=1, tw=8, seed=logn, inplace=True)
 
 
-@pytest.mark.parametrize("ov", [(8, 4), (8, 5), (7, 6), (8, 7), (8, 8), (9, 4), (10, 4), (11, 5), (12, 4), (5, 4), (4, 6),
+@pytest.mark.parametrize("ov", [(8, 4), (8, 5), (7, 6), (8, 7), (8, 8), (9, 4), (10, 4), (11, 5), (12, 4), (5, 4), (4, 6), (5, 6), (6, 7),
                                 (5, 5, 8)])
 def test_every_tile_shape(oracle, ov):
     logn = sum(ov)
     for wb, p, g in FIELDS[:2]:
+        if wb == 4 and ov[0] < 5:  # column tiles of 4-byte words are 32 words wide: first pass >= 5 stages
+            continue
         for inv in (0, 1):
             _run(oracle, wb, logn, p, g, 2, inverse=inv, scale=inv, tw=4, ov=emu_lib.pack_passes(*ov), seed=7)
 
