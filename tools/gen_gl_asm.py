@@ -23,7 +23,10 @@ across a statement and the carry was lost).
 """
 import sys
 
+import os
+
 SGPR_DIST = 3  # producer slot + 3 <= consumer slot  (two instructions in between)
+M32_VBASE = int(os.environ.get("M32_VBASE", "72"))  # first of the 8 fixed VGPRs of the 4-byte-word streams
 
 
 class Ins:
@@ -106,7 +109,7 @@ def butterfly(kind, b, vbase=108):
     return ins
 
 
-def butterfly32(kind, b, small, vbase=96):
+def butterfly32(kind, b, small, vbase=None):
     """4-byte-word Montgomery butterfly `b` (R = 2^32, twiddle in Montgomery form).
     small = True: p < 2^31, conditional corrections by v_min_u32 (no carries, no SGPRs);
     small = False: any odd p < 2^32, carries in SGPR pairs.  Operands: x y t (compiler),
@@ -160,7 +163,7 @@ def butterfly32(kind, b, small, vbase=96):
     return ins
 
 
-def emit32(kind, nb, small, vbase=96):
+def emit32(kind, nb, small, vbase=M32_VBASE):
     lists = [butterfly32(kind, b, small, vbase) for b in range(nb)]
     lines = schedule(lists)
     nops = sum(1 for l in lines if l.startswith("s_nop"))
