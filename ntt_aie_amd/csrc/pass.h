@@ -107,7 +107,10 @@ struct PassCfg {
     // straight into a second LDS buffer by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no VALU)
     // while the current one is transformed, so no wave ever waits on HBM in steady state.  The
     // DMA writes 1 KiB per wave-instruction linearly, hence these tiles are not padded.
-    static constexpr bool DMA = WAVE_LOCAL && !INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8;
+    // (Wider units, 512-thread kernels: the first round still reads exactly the words the wave's own
+    // DMA fetched -- thread t owns words [E*t, E*t+E), wave w words [64*E*w, 64*E*(w+1)) -- so the
+    // hand-off needs no barrier there either; the exchanges of the later rounds keep theirs.)
+    static constexpr bool DMA = CONTIG && !INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8;
     // column passes of 8-byte words: the NEXT polynomial's 16 words per thread are loaded into a second
     // register set while the current one is transformed (experiment knob NTT_COL_PREFETCH)
     static constexpr bool REG_PREFETCH = NTT_COL_PREFETCH && !CONTIG && sizeof(W) == 8 && LOG_M_ == 8;
