@@ -86,13 +86,21 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # rehearsal on a one-GPU box (tests only): NTT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # NTT_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device
+    if os.environ.get("NTT_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("NTT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ntt_aie_amd.dist import ShardedNTT
 

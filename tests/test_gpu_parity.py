@@ -423,3 +423,32 @@ def test_cxx_host_through_c_abi(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "PASS!" in out.stdout and len([l for l in out.stdout.splitlines() if l.strip().isdigit()]) == 10
+
+
+def test_bench_two_ranks_rehearsal():
+    """The driver's multi-GPU launch line with two ranks, rehearsed on this one-GPU box: both ranks on
+    cuda:0 and gloo instead of RCCL (which refuses two ranks on one device).  Everything else --
+    table broadcast from rank 0, per-rank shards, barrier + max-over-ranks timing, the one JSON line
+    of rank 0 with the whole-job aggregate -- is the code the 8-GPU run executes."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, NTT_BENCH_ONE_DEVICE="1", NTT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 256 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6  # whole-job aggregate
+    assert "cpu_baseline" not in d  # rank 0 at N=1 only
