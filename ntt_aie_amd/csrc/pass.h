@@ -62,7 +62,7 @@ NTT_HD void static_for(Fn &&f) {
 }
 
 template <class F_, int LOG_M_, int LOG_C_, bool CONTIG_, bool INV_, int PRELOAD_MASK_ = 0xF, int LOG_E_ = 4,
-          int LOG_NT_ = LOG_NT>
+          int LOG_NT_ = LOG_NT, bool ALLOW_DMA_ = true>
 struct PassCfg {
     using F = F_;
     using W = typename F::W;
@@ -110,7 +110,9 @@ struct PassCfg {
     // (Wider units, 512-thread kernels: the first round still reads exactly the words the wave's own
     // DMA fetched -- thread t owns words [E*t, E*t+E), wave w words [64*E*w, 64*E*(w+1)) -- so the
     // hand-off needs no barrier there either; the exchanges of the later rounds keep theirs.)
-    static constexpr bool DMA = CONTIG && !INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8;
+    // ALLOW_DMA_ = false: the same radix-8 kernel with the tile staged by ordinary loads (phase_linear),
+    // which is where a fused pointwise product has room to multiply.
+    static constexpr bool DMA = ALLOW_DMA_ && CONTIG && !INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8;
     // column passes of 8-byte words: the NEXT polynomial's 16 words per thread are loaded into a second
     // register set while the current one is transformed (experiment knob NTT_COL_PREFETCH)
     static constexpr bool REG_PREFETCH = NTT_COL_PREFETCH && !CONTIG && sizeof(W) == 8 && LOG_M_ == 8;
@@ -130,15 +132,14 @@ struct PassCfg {
 // Radix of the register rounds of a CONTIG pass.  Goldilocks passes of 7-9 stages that are not
 // the last pass of the plan run radix-8 rounds (3+3+2 or 3+3+3 stages; a unit is at most one wave): 16 data + 34 twiddle registers
 // instead of 32 + 60, so ~5 waves per SIMD hide the HBM latency that 3 waves could not.
-constexpr int contig_log_e(int log_m, int word_bytes, bool last_pass, bool fused_product = false) {
-    // (the LDS-DMA kernel has no place to multiply: a fused pointwise product takes the radix-16 kernel)
-    return (word_bytes == 8 && !last_pass && !fused_product && log_m >= 7) ? 3 : 4;
+constexpr int contig_log_e(int log_m, int word_bytes, bool last_pass) {
+    return (word_bytes == 8 && !last_pass && log_m >= 7) ? 3 : 4;
 }
 // ... and 10-12 stages run radix-8 too, in 512-thread workgroups (a unit of 1024-4096 words spans 2-8
 // waves): all 28 twiddles of the four rounds stay in registers, where the radix-16 kernel had to reload 30-45
 // of them from L2 for every polynomial.
-constexpr int contig_log_nt(int log_m, int word_bytes, bool last_pass, bool fused_product = false) {
-    return (contig_log_e(log_m, word_bytes, last_pass, fused_product) == 3 && log_m >= 10) ? 9 : 8;
+constexpr int contig_log_nt(int log_m, int word_bytes, bool last_pass) {
+    return (contig_log_e(log_m, word_bytes, last_pass) == 3 && log_m >= 10) ? 9 : 8;
 }
 
 // Column tile: 2^LOG_C consecutive words per row segment = one 128-byte line either way:

@@ -123,7 +123,17 @@ int dispatch(bool contig, int log_m, const Erased &e) {
     case M:         \
         return run_cfg<ColPassCfg<F, M, INV>>(e);
     if (contig) {
-        if (contig_log_e(log_m, sizeof(typename F::W), e.s0 + log_m == e.n, e.in2 != nullptr) == 3) {
+        if (contig_log_e(log_m, sizeof(typename F::W), e.s0 + log_m == e.n) == 3) {
+            if constexpr (!INV) {
+                if (e.in2 != nullptr) {  // fused product: the non-DMA twins (pass_kernel.inc)
+                    if (log_m == 7) return run_cfg<PassCfg<F, 7, 0, true, INV, 0xF, 3, 8, false>>(e);
+                    if (log_m == 8) return run_cfg<PassCfg<F, 8, 0, true, INV, 0xF, 3, 8, false>>(e);
+                    if (log_m == 9) return run_cfg<PassCfg<F, 9, 0, true, INV, 0xF, 3, 8, false>>(e);
+                    if (log_m == 10) return run_cfg<PassCfg<F, 10, 0, true, INV, 0xF, 3, 9, false>>(e);
+                    if (log_m == 11) return run_cfg<PassCfg<F, 11, 0, true, INV, 0xF, 3, 9, false>>(e);
+                    return run_cfg<PassCfg<F, 12, 0, true, INV, 0xF, 3, 9, false>>(e);
+                }
+            }
             if (log_m == 7) return run_cfg<PassCfg<F, 7, 0, true, INV, 0xF, 3>>(e);
             if (log_m == 8) return run_cfg<PassCfg<F, 8, 0, true, INV, 0xF, 3>>(e);
             if (log_m == 9) return run_cfg<PassCfg<F, 9, 0, true, INV, 0xF, 3>>(e);

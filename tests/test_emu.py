@@ -105,7 +105,7 @@ def test_fused_pointwise_first_pass(oracle):
     """forward(in * in2 * scale) with the product folded into the first pass's load."""
     for wb, p, g in FIELDS[:2]:
         dt = np.uint32 if wb == 4 else np.uint64
-        for logn in (2, 4, 6, 10, 13):
+        for logn in (2, 4, 6, 10, 13, 16, 17, 18):  # 13/16/17/18: radix-8 first passes of 7/8/9/10 stages
             n = 1 << logn
             T = oracle.make_roots(n, p, g, wb)
             rng = np.random.default_rng(logn)
