@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libntt_hip.so")
+# NTT_HIP_LIB: A/B experiments load another build of the same library (tools/README.md)
+LIB_PATH = os.environ.get("NTT_HIP_LIB") or os.path.join(_HERE, "libntt_hip.so")
 
 # error codes of include/ntt_hip.h
 NTT_OK = 0

@@ -41,6 +41,9 @@
 #ifndef NTT_COL_PREFETCH
 #define NTT_COL_PREFETCH 0  // experiment knob: register prefetch in the 8-stage column pass
 #endif
+#ifndef NTT_INV_PREFETCH
+#define NTT_INV_PREFETCH 0  // experiment knob: register prefetch in the inverse CONTIG radix-8 passes (measured: no gain)
+#endif
 
 namespace ntt {
 
@@ -115,7 +118,9 @@ struct PassCfg {
     static constexpr bool DMA = ALLOW_DMA_ && CONTIG && !INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8;
     // column passes of 8-byte words: the NEXT polynomial's 16 words per thread are loaded into a second
     // register set while the current one is transformed (experiment knob NTT_COL_PREFETCH)
-    static constexpr bool REG_PREFETCH = NTT_COL_PREFETCH && !CONTIG && sizeof(W) == 8 && LOG_M_ == 8;
+    // ... and the inverse CONTIG radix-8 passes (direct loads of 8 words per thread, no DMA): NTT_INV_PREFETCH
+    static constexpr bool REG_PREFETCH = (NTT_COL_PREFETCH && !CONTIG && sizeof(W) == 8 && LOG_M_ == 8) ||
+                                         (NTT_INV_PREFETCH && CONTIG && INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8);
 
     static NTT_HD uint32_t lds_index(uint32_t lin) { return DMA ? lin : lin + ((lin >> LOG_E) * VW); }
 };
