@@ -452,3 +452,58 @@ def test_bench_two_ranks_rehearsal():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 256 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6  # whole-job aggregate
     assert "cpu_baseline" not in d  # rank 0 at N=1 only
+
+
+def test_large_sizes_against_oracle(eng, oracle):
+    """N = 2^24 (8+8+8) and 2^26 (12+7+7), 4-byte words, one polynomial each: word-exact against the oracle."""
+    import torch
+
+    p, g = 3221225473, 5  # 3*2^30 + 1
+    for logn in (24, 26):
+        n = 1 << logn
+        pl = eng.NTTPlan(logn, p, 4, 0)
+        pl.generate_twiddles(0, g)  # make_roots rule, on the device
+        T = pl.get_twiddles()
+        assert np.array_equal(T[:4], oracle.make_roots(n, p, g, 4)[:4])
+        a = _rand(1, n, p, np.uint32, logn)
+        want = oracle.ntt(a, T, p, nthreads=1)
+        d = eng.to_device(a, "cuda:0")
+        f = pl.forward(d)
+        assert np.array_equal(eng.to_host(f), want)
+        assert np.array_equal(eng.to_host(pl.inverse(f)), a)
+        del d, f
+        torch.cuda.empty_cache()
+
+
+def test_maximum_size_properties(eng):
+    """N = 2^28 (the largest plan, 12+8+8), Goldilocks, 2 GiB per polynomial: size-independent properties --
+    inverse(forward(a)) == a, forward(a + b) == forward(a) + forward(b), and one output word against the
+    definition (the last stage's first butterfly sums everything: out[0] = sum(a) mod p)."""
+    import torch
+
+    logn, p = 28, GOLD
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, 8, 0)
+    pl.generate_twiddles(0, 7)
+    assert pl.hbm_passes == 3
+    g = torch.Generator(device="cuda:0").manual_seed(28)
+    a = torch.randint(0, 1 << 62, (1, n), dtype=torch.int64, device="cuda:0", generator=g)
+    b = torch.randint(0, 1 << 62, (1, n), dtype=torch.int64, device="cuda:0", generator=g)
+    fa = pl.forward(a)
+    assert pl.count_noncanonical(fa) == 0
+    # out[0] is the plain sum of all inputs (every stage's "x + y" leg)
+    ah = a.cpu().numpy().view(np.uint64).ravel()
+    s = int(np.sum(ah >> np.uint64(32), dtype=np.uint64)) * (1 << 32) + int(np.sum(ah & np.uint64(0xFFFFFFFF), dtype=np.uint64))
+    assert int(fa.cpu().numpy().view(np.uint64)[0, 0]) == s % p
+    assert torch.equal(pl.inverse(fa), a)
+    fb = pl.forward(b)
+    ab = (a + b)  # < 2^63 < p
+    fab = pl.forward(ab)
+    # modular sum of the two transforms on the device: (fa + fb) mod p with 64-bit wraparound handled
+    x, y = fa.view(torch.int64), fb.view(torch.int64)
+    ssum = x + y
+    carry = ((x < 0) & (y < 0)) | (((x < 0) | (y < 0)) & (ssum >= 0))  # unsigned overflow of x + y
+    ssum = torch.where(carry, ssum + 0xFFFFFFFF, ssum)                # 2^64 = 2^32 - 1 (mod p)
+    ge_p = (ssum < 0) & (ssum >= torch.tensor(p - (1 << 64), dtype=torch.int64, device="cuda:0"))
+    ssum = torch.where(ge_p, ssum - torch.tensor(p - (1 << 64), dtype=torch.int64, device="cuda:0"), ssum)
+    assert torch.equal(ssum, fab.view(torch.int64))
