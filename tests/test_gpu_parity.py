@@ -507,3 +507,24 @@ def test_maximum_size_properties(eng):
     ge_p = (ssum < 0) & (ssum >= torch.tensor(p - (1 << 64), dtype=torch.int64, device="cuda:0"))
     ssum = torch.where(ge_p, ssum - torch.tensor(p - (1 << 64), dtype=torch.int64, device="cuda:0"), ssum)
     assert torch.equal(ssum, fab.view(torch.int64))
+
+
+def test_batch_beyond_grid_limit(eng):
+    """N = 2, 4-byte words, batch just above 65535 * 64 * 256 polynomials: more polynomial groups than
+    blockIdx.y can number, so the launch is sliced (pass_kernel.inc:launch_cfg).  8.6 GB per buffer; the
+    expected words come from the definition (src/test.cpp:46-50) evaluated with torch integer arithmetic."""
+    import torch
+
+    p, g = 3329, 3
+    batch = 65535 * 64 * 256 + 777
+    pl = eng.NTTPlan(1, p, 4, 0)
+    T = pl.make_roots(g)
+    pl.set_twiddles(T)
+    gen = torch.Generator(device="cuda:0").manual_seed(5)
+    a = torch.randint(0, p, (batch, 2), dtype=torch.int32, device="cuda:0", generator=gen)
+    out = pl.forward(a)
+    a0, a1 = a[:, 0].to(torch.int64), a[:, 1].to(torch.int64)
+    assert torch.equal(out[:, 0].to(torch.int64), (a0 + a1) % p)
+    assert torch.equal(out[:, 1].to(torch.int64), ((a0 - a1) % p) * int(T[1]) % p)
+    del a0, a1
+    assert torch.equal(pl.inverse(out), a)
