@@ -299,13 +299,14 @@ int ntt_plan_generate_twiddles(ntt_plan_t pl, int kind, uint64_t g) {
     uint64_t base;
     if (kind == 2) {
         if ((p - 1) % (2 * N)) return NTT_E_ARG;
-        base = powmod(powmod(g, (p - 1) / (2 * N), p), p - 2, p);  // psi^-1
+        base = invmod(powmod(g, (p - 1) / (2 * N), p), p);  // psi^-1
     } else {
         if (kind == 1 && (p - 1) % N) return NTT_E_ARG;
         base = powmod(g, (p - 1) / N, p);                           // w (integer division, src/test.cpp:28)
     }
     if (base == 0) return NTT_E_NOTINVERTIBLE;
-    const uint64_t base_inv = powmod(base, p - 2, p);
+    const uint64_t base_inv = invmod(base, p);
+    if (base_inv == 0) return NTT_E_NOTINVERTIBLE;
     const int wb = pl->word_bytes;
     const uint64_t one_m = to_table_form(1 % p, p, wb);
     DeviceGuard g_(pl->device);
@@ -340,7 +341,7 @@ int ntt_plan_get_twiddles(ntt_plan_t pl, int inverse, void *host_T) {
     // table (Montgomery) form -> plain residues: x * R^-1
     const size_t N = (size_t) 1 << pl->logn;
     const uint64_t p = pl->p;
-    const uint64_t rinv = powmod(to_table_form(1 % p, p, pl->word_bytes), p - 2, p);
+    const uint64_t rinv = invmod(to_table_form(1 % p, p, pl->word_bytes), p);  // R is a power of two, p odd: always a unit
     for (size_t i = 0; i < N; i++) {
         if (pl->word_bytes == 4) ((uint32_t *) host_T)[i] = (uint32_t) mulmod(((uint32_t *) host_T)[i], rinv, p);
         else ((uint64_t *) host_T)[i] = mulmod(((uint64_t *) host_T)[i], rinv, p);

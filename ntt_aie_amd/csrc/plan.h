@@ -34,6 +34,21 @@ inline uint64_t powmod(uint64_t x, uint64_t e, uint64_t p) {
     return r;
 }
 
+// a^-1 mod p by the extended Euclidean algorithm; 0 when gcd(a, p) != 1.  (Not Fermat: the reference
+// never checks that its modulus is prime, and the 4-byte-word engine accepts any odd p.)
+inline uint64_t invmod(uint64_t a, uint64_t p) {
+    typedef __int128 i128;
+    i128 r0 = (i128) p, r1 = (i128) (a % p), t0 = 0, t1 = 1;
+    while (r1 != 0) {
+        const i128 q = r0 / r1;
+        const i128 r2 = r0 - q * r1, t2 = t0 - q * t1;
+        r0 = r1; r1 = r2; t0 = t1; t1 = t2;
+    }
+    if (r0 != 1) return 0;
+    if (t0 < 0) t0 += (i128) p;
+    return (uint64_t) t0;
+}
+
 inline uint64_t bitrev(uint64_t x, int bits) {
     uint64_t r = 0;
     for (int i = 0; i < bits; i++) r |= ((x >> i) & 1ULL) << (bits - 1 - i);
@@ -89,7 +104,8 @@ inline bool invert_table(const std::vector<uint64_t> &T, uint64_t p, std::vector
         pre[i] = acc;
         acc = mulmod(acc, T[i], p);
     }
-    uint64_t inv = powmod(acc, p - 2, p);
+    uint64_t inv = invmod(acc, p);
+    if (inv == 0) return false;  // some entry shares a factor with p
     for (size_t i = N; i-- > 1;) {
         Ti[i] = mulmod(inv, pre[i], p);
         inv = mulmod(inv, T[i], p);
@@ -124,7 +140,8 @@ inline bool make_table(int kind, int logn, uint64_t p, uint64_t g, std::vector<u
     if (kind == 2) {
         if ((p - 1) % (2 * N)) return false;
         const uint64_t psi = powmod(g, (p - 1) / (2 * N), p);
-        const uint64_t psi_inv = powmod(psi, p - 2, p);
+        const uint64_t psi_inv = invmod(psi, p);
+        if (psi_inv == 0) return false;
         std::vector<uint64_t> pw(N);
         pw[0] = 1;
         for (uint64_t i = 1; i < N; i++) pw[i] = mulmod(pw[i - 1], psi_inv, p);

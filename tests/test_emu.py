@@ -117,3 +117,22 @@ def test_fused_pointwise_first_pass(oracle):
                                                    out.ctypes.data, 3, scale, 8)
             assert rc == 0
             assert np.array_equal(out, oracle.ntt(oracle.pointwise(a, b, p, scale), T, p)), (wb, logn)
+
+
+def test_composite_odd_modulus(oracle):
+    """The reference never checks that p is prime and the 4-byte-word engine takes any odd modulus: the
+    forward network is the same words as the oracle's `%` arithmetic, and the inverse exists whenever every
+    table entry is a unit (inverses by extended Euclid, not Fermat)."""
+    p = 3 * 3329
+    for logn in (6, 13):
+        for inv in (0, 1):
+            _run(oracle, 4, logn, p, 2, 3, inverse=inv, seed=logn)  # g = 2: every power is a unit mod 9987
+    # g = 3 shares a factor with p: forward still defined, inverse refused
+    n = 64
+    T = oracle.make_roots(n, p, 3, 4)
+    a = np.arange(n, dtype=np.uint32)[None, :]
+    out = np.zeros_like(a)
+    L = emu_lib.lib()
+    assert L.emu_transform(4, 6, p, T.ctypes.data, a.ctypes.data, out.ctypes.data, 1, 0, 0, 1, 2048, 0) == 0
+    assert np.array_equal(out, oracle.ntt(a, T, p))
+    assert L.emu_transform(4, 6, p, T.ctypes.data, a.ctypes.data, out.ctypes.data, 1, 1, 0, 1, 2048, 0) == -5

@@ -528,3 +528,25 @@ def test_batch_beyond_grid_limit(eng):
     assert torch.equal(out[:, 1].to(torch.int64), ((a0 - a1) % p) * int(T[1]) % p)
     del a0, a1
     assert torch.equal(pl.inverse(out), a)
+
+
+def test_composite_odd_modulus(eng, oracle):
+    """Any odd modulus below 2^32 (the reference never checks primality): forward == oracle; the inverse exists
+    when every table entry is a unit and is refused (NTT_E_NOTINVERTIBLE) otherwise."""
+    p = 3 * 3329
+    for logn in (6, 13):
+        n = 1 << logn
+        T = oracle.make_roots(n, p, 2, 4)
+        pl = _plan(eng, logn, p, 4, T)
+        a = _rand(5, n, p, np.uint32, logn)
+        f = pl.forward(eng.to_device(a, "cuda:0"))
+        assert np.array_equal(eng.to_host(f), oracle.ntt(a, T, p))
+        assert np.array_equal(eng.to_host(pl.inverse(f)), a)
+    T = oracle.make_roots(64, p, 3, 4)  # powers of 3: not units mod 9987
+    pl = _plan(eng, 6, p, 4, T)
+    a = _rand(2, 64, p, np.uint32, 1)
+    f = pl.forward(eng.to_device(a, "cuda:0"))
+    assert np.array_equal(eng.to_host(f), oracle.ntt(a, T, p))
+    with pytest.raises(eng.NTTError) as ei:
+        pl.inverse(f)
+    assert ei.value.code == -5  # NTT_E_NOTINVERTIBLE
