@@ -38,12 +38,12 @@ def is_sgpr(r):
     return r.startswith("s") or r == "vcc"
 
 
-def butterfly(kind, b, vbase=108):
+def butterfly(kind, b, vbase=104):
     """Instruction list of butterfly `b` (0/1).  kind: 'fwd' | 'inv' | 'mul'.
     Operand names: x0 x1 y0 y1 t0 t1 (compiler operands, suffixed by b), temporaries
-    d0 d1 z0 z1 u0 u1 (operands), fixed pairs L M A B H, SGPR pairs sa sb se sf."""
-    vb = vbase + 10 * b
-    L, M, A, B, H = [(f"v{vb + 2 * i}", f"v{vb + 2 * i + 1}") for i in range(5)]
+    d0 d1 (operands), fixed pairs L M A B H Z, SGPR pairs sa sb se sf."""
+    vb = vbase + 12 * b
+    L, M, A, B, H, Z = [(f"v{vb + 2 * i}", f"v{vb + 2 * i + 1}") for i in range(6)]
     sb_ = 84 + 8 * b
     sa, sbb, se, sf = [f"s[{sb_ + 2 * i}:{sb_ + 2 * i + 1}]" for i in range(4)]
 
@@ -55,7 +55,7 @@ def butterfly(kind, b, vbase=108):
         return f"%[{name}{b}]"
 
     x0, x1, y0, y1, t0, t1 = o("x0_"), o("x1_"), o("y0_"), o("y1_"), o("t0_"), o("t1_")
-    d0, d1, z0, z1, u0, u1 = o("d0_"), o("d1_"), o("z0_"), o("z1_"), o("u0_"), o("u1_")
+    d0, d1 = o("d0_"), o("d1_")
     ins = []
 
     def sub(dst0, dst1, a0, a1, b0, b1, tmp0, tmp1, final0, final1):
@@ -67,14 +67,15 @@ def butterfly(kind, b, vbase=108):
         ins.append(Ins(f"v_subbrev_co_u32 {final1}, {sa}, 0, {tmp1}, {sa}", [tmp1, sa], [final1, sa]))
 
     def add(a0, a1, b0, b1, out0, out1):
-        # (a + b) mod p: sum, sum + (2^32-1), pick the second when either carried
-        ins.append(Ins(f"v_add_co_u32 {z0}, {se}, {a0}, {b0}", [a0, b0], [z0, se]))
-        ins.append(Ins(f"v_addc_co_u32 {z1}, {se}, {a1}, {b1}, {se}", [a1, b1, se], [z1, se]))
-        ins.append(Ins(f"v_add_co_u32 {u0}, {sf}, -1, {z0}", [z0], [u0, sf]))
-        ins.append(Ins(f"v_addc_co_u32 {u1}, {sf}, 0, {z1}, {sf}", [z1, sf], [u1, sf]))
+        # (a + b) mod p, canonical: z = a + b (carry c); e = c | (z >= p) by ONE 64-bit compare; out = z + e*(2^32-1)
+        # as out0 = z0 - e (borrow g), out1 = z1 + (e & ~g).  5 VALU + 2 SALU (was 6 + 1 with two selects).
+        ins.append(Ins(f"v_add_co_u32 {Z[0]}, {se}, {a0}, {b0}", [a0, b0], [Z[0], se]))
+        ins.append(Ins(f"v_addc_co_u32 {Z[1]}, {se}, {a1}, {b1}, {se}", [a1, b1, se], [Z[1], se]))
+        ins.append(Ins(f"v_cmp_le_u64 {sf}, %[pp], {P(Z)}", [Z[0], Z[1]], [sf]))
         ins.append(Ins(f"s_or_b64 {se}, {se}, {sf}", [se, sf], [se], salu=True))
-        ins.append(Ins(f"v_cndmask_b32 {out0}, {z0}, {u0}, {se}", [z0, u0, se], [out0]))
-        ins.append(Ins(f"v_cndmask_b32 {out1}, {z1}, {u1}, {se}", [z1, u1, se], [out1]))
+        ins.append(Ins(f"v_subbrev_co_u32 {out0}, {sf}, 0, {Z[0]}, {se}", [Z[0], se], [out0, sf]))
+        ins.append(Ins(f"s_andn2_b64 {se}, {se}, {sf}", [se, sf], [se], salu=True))
+        ins.append(Ins(f"v_addc_co_u32 {out1}, {sf}, {Z[1]}, 0, {se}", [Z[1], se], [out1, sf]))
 
     def mul(m0, m1, r0, r1):
         # (m1:m0) * (t1:t0) * 2^-64 mod p, canonical; m may be any 64-bit value
@@ -243,7 +244,7 @@ def schedule(lists):
     return out
 
 
-def emit(kind, nb, tw_constraint, vbase=108, suffix=""):
+def emit(kind, nb, tw_constraint, vbase=104, suffix=""):
     lists = [butterfly(kind, b, vbase) for b in range(nb)]
     lines = schedule(lists)
     nops = sum(1 for l in lines if l.startswith("s_nop"))
@@ -262,7 +263,7 @@ def emit(kind, nb, tw_constraint, vbase=108, suffix=""):
             src.append(f"    uint32_t y0_{b} = (uint32_t) y{b}, y1_{b} = (uint32_t) (y{b} >> 32);")
         src.append(f"    const uint32_t t0_{b} = (uint32_t) t{b}, t1_{b} = (uint32_t) (t{b} >> 32);")
         if kind != "mul":
-            src.append(f"    uint32_t d0_{b}, d1_{b}, z0_{b}, z1_{b}, u0_{b}, u1_{b};")
+            src.append(f"    uint32_t d0_{b}, d1_{b};")
     src.append("    asm volatile(")
     for l in lines:
         src.append(f'        "{l}\\n\\t"')
@@ -271,9 +272,11 @@ def emit(kind, nb, tw_constraint, vbase=108, suffix=""):
         outs += [f'[x0_{b}] "+v"(x0_{b})', f'[x1_{b}] "+v"(x1_{b})']
         if kind != "mul":
             outs += [f'[y0_{b}] "+v"(y0_{b})', f'[y1_{b}] "+v"(y1_{b})']
-            outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("d0_", "d1_", "z0_", "z1_", "u0_", "u1_")]
+            outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("d0_", "d1_")]
         ins_ += [f'[t0_{b}] "{tw_constraint}"(t0_{b})', f'[t1_{b}] "{tw_constraint}"(t1_{b})']
-    clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 10 * nb)] + [f'"s{r}"' for r in range(84, 84 + 8 * nb)]
+    if kind != "mul":
+        ins_ += ['[pp] "s"(0xFFFFFFFF00000001ull)']  # p, for the 64-bit compare of the modular add
+    clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 12 * nb)] + [f'"s{r}"' for r in range(84, 84 + 8 * nb)]
     src.append("        : " + ", ".join(outs))
     src.append("        : " + ", ".join(ins_))
     src.append("        : " + ", ".join(clob) + ");")
@@ -298,7 +301,7 @@ def main():
             out.append("")
             print(f"{kind} x2 tw={tw}: {n} instructions, {nops} nops", file=sys.stderr)
         if kind != "mul":
-            txt, n, nops = emit(kind, 2, "v", vbase=76, suffix="_lo")  # for the radix-8 (light) kernels
+            txt, n, nops = emit(kind, 2, "v", vbase=72, suffix="_lo")  # for the radix-8 (light) kernels
             out.append(txt)
             out.append("")
     for kind in ("fwd32", "inv32"):

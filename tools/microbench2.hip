@@ -62,6 +62,16 @@ KERNEL(k_pk_add_u16, W8("v_pk_add_u16", ", %16"))
 KERNEL(k_dot4_u32_u8, W8("v_dot4_u32_u8", ", %16, %17"))
 KERNEL(k_add_dpp, "v_add_u32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" "v_add_u32_dpp %1, %2, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" "v_add_u32_dpp %2, %3, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" "v_add_u32_dpp %3, %4, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" "v_add_u32_dpp %4, %5, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" "v_add_u32_dpp %5, %6, %5 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" "v_add_u32_dpp %6, %7, %6 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" "v_add_u32_dpp %7, %0, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n")
 
+KERNEL(k_cmp_ge_u64_sgpr, "v_cmp_ge_u64 s[20:21], %8, %9\n" "v_cmp_ge_u64 s[22:23], %9, %10\n" "v_cmp_ge_u64 s[24:25], %10, %11\n" "v_cmp_ge_u64 s[26:27], %11, %12\n" "v_cmp_ge_u64 s[20:21], %12, %13\n" "v_cmp_ge_u64 s[22:23], %13, %14\n" "v_cmp_ge_u64 s[24:25], %14, %15\n" "v_cmp_ge_u64 s[26:27], %15, %8\n")
+KERNEL(k_cmp_le_u64_sconst, "v_cmp_le_u64 s[20:21], s[26:27], %8\n" "v_cmp_le_u64 s[22:23], s[26:27], %9\n" "v_cmp_le_u64 s[24:25], s[26:27], %10\n" "v_cmp_le_u64 s[20:21], s[26:27], %11\n" "v_cmp_le_u64 s[22:23], s[26:27], %12\n" "v_cmp_le_u64 s[24:25], s[26:27], %13\n" "v_cmp_le_u64 s[20:21], s[26:27], %14\n" "v_cmp_le_u64 s[22:23], s[26:27], %15\n")
+KERNEL(k_cndmask_sgpr, "v_cndmask_b32 %0, %0, %16, s[20:21]\n" "v_cndmask_b32 %1, %1, %16, s[22:23]\n" "v_cndmask_b32 %2, %2, %16, s[24:25]\n" "v_cndmask_b32 %3, %3, %16, s[26:27]\n" "v_cndmask_b32 %4, %4, %16, s[20:21]\n" "v_cndmask_b32 %5, %5, %16, s[22:23]\n" "v_cndmask_b32 %6, %6, %16, s[24:25]\n" "v_cndmask_b32 %7, %7, %16, s[26:27]\n")
+KERNEL(k_subbrev_sgpr, "v_subbrev_co_u32 %0, s[20:21], 0, %0, s[20:21]\n" "v_subbrev_co_u32 %1, s[22:23], 0, %1, s[22:23]\n" "v_subbrev_co_u32 %2, s[24:25], 0, %2, s[24:25]\n" "v_subbrev_co_u32 %3, s[26:27], 0, %3, s[26:27]\n" "v_subbrev_co_u32 %4, s[20:21], 0, %4, s[20:21]\n" "v_subbrev_co_u32 %5, s[22:23], 0, %5, s[22:23]\n" "v_subbrev_co_u32 %6, s[24:25], 0, %6, s[24:25]\n" "v_subbrev_co_u32 %7, s[26:27], 0, %7, s[26:27]\n")
+KERNEL(k_mad_u64_add1, "v_mad_u64_u32 %8, vcc, %0, 1, %8\n" "v_mad_u64_u32 %9, vcc, %1, 1, %9\n" "v_mad_u64_u32 %10, vcc, %2, 1, %10\n" "v_mad_u64_u32 %11, vcc, %3, 1, %11\n" "v_mad_u64_u32 %12, vcc, %4, 1, %12\n" "v_mad_u64_u32 %13, vcc, %5, 1, %13\n" "v_mad_u64_u32 %14, vcc, %6, 1, %14\n" "v_mad_u64_u32 %15, vcc, %7, 1, %15\n")
+KERNEL(k_not_b32, "v_not_b32 %0, %0\n" "v_not_b32 %1, %1\n" "v_not_b32 %2, %2\n" "v_not_b32 %3, %3\n" "v_not_b32 %4, %4\n" "v_not_b32 %5, %5\n" "v_not_b32 %6, %6\n" "v_not_b32 %7, %7\n")
+KERNEL(k_sub_sgpr, W8("v_subrev_u32", ", %18"))
+KERNEL(k_max_u32, W8("v_max_u32", ", %16"))
+KERNEL(k_cmp_ne_u32_sgpr, "v_cmp_ne_u32 s[20:21], 0, %0\n" "v_cmp_ne_u32 s[22:23], 0, %1\n" "v_cmp_ne_u32 s[24:25], 0, %2\n" "v_cmp_ne_u32 s[26:27], 0, %3\n" "v_cmp_ne_u32 s[20:21], 0, %4\n" "v_cmp_ne_u32 s[22:23], 0, %5\n" "v_cmp_ne_u32 s[24:25], 0, %6\n" "v_cmp_ne_u32 s[26:27], 0, %7\n")
+
 template <class K>
 double run(K kern, uint32_t *d_out) {
     const int blocks = 512, threads = 1024;  // 8 waves per SIMD
@@ -89,5 +99,6 @@ int main() {
     R(k_mul_hi_u32_u24) R(k_mad_u32_u24) R(k_mul_lo_u32) R(k_mul_hi_u32) R(k_add_co_vcc) R(k_add_co_sgpr)
     R(k_addc_vcc) R(k_cndmask_vcc) R(k_cmp_lt_u32_vcc) R(k_mad_u64_u32) R(k_mad_u64_u32_c0) R(k_lshl_add_u64)
     R(k_lshrrev_b64) R(k_mov_b64) R(k_fma_f32) R(k_pk_fma_f32) R(k_fma_f64) R(k_pk_add_u16) R(k_dot4_u32_u8) R(k_add_dpp)
+    R(k_cmp_ge_u64_sgpr) R(k_cmp_le_u64_sconst) R(k_cndmask_sgpr) R(k_subbrev_sgpr) R(k_mad_u64_add1) R(k_not_b32) R(k_sub_sgpr) R(k_max_u32) R(k_cmp_ne_u32_sgpr)
     return 0;
 }
