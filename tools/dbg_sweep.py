@@ -10,7 +10,7 @@ from ntt_aie_amd import NTTPlan
 logn, wb = int(sys.argv[1]), int(sys.argv[2])
 if len(sys.argv) > 3:
     os.environ["NTT_PLAN_SPLIT"] = sys.argv[3]
-p, g = (0xFFFFFFFF00000001, 7) if wb == 8 else (3221225473, 5)
+p, g = (0xFFFFFFFF00000001, 7) if wb == 8 else ((3221225473, 5) if os.environ.get("NTT_SWEEP_SMALL_P") != "1" else (12289, 11))
 batch = (1 << (32 - (3 if wb == 8 else 2))) >> logn  # 4 GiB of coefficients
 gen = torch.Generator(device="cuda:0").manual_seed(1)
 x = torch.randint(0, p if wb == 4 else 1 << 62, (batch, 1 << logn), dtype=torch.int64, device="cuda:0", generator=gen)
