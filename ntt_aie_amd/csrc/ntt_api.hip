@@ -2,6 +2,8 @@
 // twiddle preparation and launch sequencing.  Host side of what the reference
 // does in src/test.cpp:62-190 (buffers, table, launch) minus XRT.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -26,6 +28,47 @@ struct DeviceGuard {
     ~DeviceGuard() {
         int cur = -1;
         if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void) hipSetDevice(prev);
+    }
+};
+
+// ROCTX ranges around every transform and every HBM pass when NTT_ROCTX=1 (rocprofv3 --marker-trace):
+// the role of the reference's trace_event0() / trace_event1() brackets (src/aie_core.cc:129-131,
+// src/aie2.py:182,312).  The ROCTX library is looked up at run time: no link-time profiler dependency.
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char *e = getenv("NTT_ROCTX");
+        if (!e || atoi(e) == 0) return;
+        // rocprofv3 listens to the rocprofiler-sdk ROCTX; libroctx64 is the older roctracer one (rocprof v1/v2)
+        void *h = nullptr;
+        for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
+        if (!h) return;
+        push = (int (*)(const char *)) dlsym(h, "roctxRangePushA");
+        pop = (int (*)()) dlsym(h, "roctxRangePop");
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const Roctx &roctx() {
+    static const Roctx r;
+    return r;
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char *name) : on(roctx().push != nullptr) {
+        if (on) roctx().push(name);
+    }
+    RoctxRange(const char *what, int contig, int s0, int log_m) : on(roctx().push != nullptr) {
+        if (!on) return;
+        char buf[96];
+        snprintf(buf, sizeof(buf), "%s %s stages %d-%d", what, contig ? "contig" : "column", s0, s0 + log_m - 1);
+        roctx().push(buf);
+    }
+    ~RoctxRange() {
+        if (on) roctx().pop();
     }
 };
 
@@ -86,6 +129,7 @@ int check_io(const ntt_plan *pl, const void *a, const void *b, size_t batch) {
 // the load of the first pass
 int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int layout, hipStream_t s,
                 const void *in2 = nullptr, uint64_t pw_scale_plain = 1) {
+    RoctxRange whole(in2 ? "ntt_forward(product)" : "ntt_forward");
     const void *src = d_in;
     const void *skip_if = nullptr;
     if (pl->d_fused_ctl && !in2 && d_in != d_out && layout == NTT_LAYOUT_NATURAL && batch >= 64 && batch % 8 == 0 &&
@@ -98,6 +142,7 @@ int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
         if (pl->dbg & (16 | 32 | 64)) return NTT_OK;  // timing experiments: fused launch alone
     }
     for (const PassDesc &pd : pl->passes) {
+        RoctxRange pass("fwd pass", pd.contig, pd.s0, pd.log_m);
         ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
         a.skip_if = skip_if;
         if (&pd == &pl->passes.front() && in2) {  // first pass only (d_out may alias d_in)
@@ -116,9 +161,11 @@ int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
 
 int run_inverse(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int layout, int scale,
                 hipStream_t s) {
+    RoctxRange whole("ntt_inverse");
     const void *src = d_in;
     for (size_t i = pl->passes.size(); i-- > 0;) {
         const PassDesc &pd = pl->passes[i];
+        RoctxRange pass("inv pass", pd.contig, pd.s0, pd.log_m);
         ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
         a.tw = pl->d_tw_inv;
         a.layout = layout;

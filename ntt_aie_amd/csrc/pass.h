@@ -512,7 +512,7 @@ __device__ __forceinline__ void glds16(const void *gptr, uint32_t lds_byte) {
 // issue the copy of the tile of iteration `it` into LDS buffer (it & 1); wave-segmented like phase_linear
 template <class Cfg>
 NTT_HD void phase_dma_issue(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *lds, int it) {
-    using W = typename Cfg::W;
+    using W [[maybe_unused]] = typename Cfg::W;  // device branch only
     constexpr int V = Cfg::VW;
     constexpr int ITER = Cfg::E / V;
     const size_t tile0 = uniform_word<Cfg>(c, a, it);

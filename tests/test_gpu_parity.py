@@ -550,3 +550,34 @@ def test_composite_odd_modulus(eng, oracle):
     with pytest.raises(eng.NTTError) as ei:
         pl.inverse(f)
     assert ei.value.code == -5  # NTT_E_NOTINVERTIBLE
+
+
+def test_roctx_ranges_under_rocprofv3(tmp_path):
+    """NTT_ROCTX=1: every transform and every HBM pass is bracketed by a ROCTX range (the role of the
+    reference's trace_event0/trace_event1, src/aie_core.cc:129-131); rocprofv3 --marker-trace must list them."""
+    import shutil
+    import subprocess
+
+    from conftest import ROOT
+
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on PATH")
+    script = tmp_path / "roctx_run.py"
+    script.write_text(
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "from ntt_aie_amd import NTTPlan, to_device\n"
+        "pl = NTTPlan(16, 0xFFFFFFFF00000001, 8, 0); pl.generate_twiddles(0, 7)\n"
+        "x = to_device(np.arange(1 << 16, dtype=np.uint64)[None, :], 'cuda:0')\n"
+        "y = pl.inverse(pl.forward(x)); torch.cuda.synchronize(); assert torch.equal(x, y)\n" % ROOT)
+    out = tmp_path / "prof"
+    env = dict(os.environ, NTT_ROCTX="1", TMPDIR="/tmp")
+    r = subprocess.run(["rocprofv3", "--marker-trace", "--kernel-trace", "--output-format", "csv", "-d", str(out), "-o", "run",
+                        "--", "python3", str(script)], capture_output=True, text=True, timeout=600, env=env, cwd="/tmp")
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    files = glob.glob(str(out / "**" / "*.csv"), recursive=True)
+    text = "".join(open(f).read() for f in files if "marker" in os.path.basename(f))
+    assert text, (files, (r.stdout + r.stderr)[-2000:])
+    for name in ("ntt_forward", "fwd pass contig stages 0-7", "fwd pass column stages 8-15", "ntt_inverse",
+                 "inv pass column stages 8-15", "inv pass contig stages 0-7"):
+        assert name in text, name
