@@ -159,11 +159,12 @@ def main():
         # same command, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_pmc_traffic.json
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        names = ["pass_contig_8", "pass_col_8"]
+        names = ["pass_%s_%d" % (kind, stages) for kind, _, stages in plan.passes]
         if os.path.exists(pmc) and logn == 16 and batch == 4096:
             k = json.load(open(pmc))["kernels"]
-            traffic = sum(k[nm]["hbm_bytes_per_launch"] for nm in names)
-            traffic_src = "profiles/r01_pmc_traffic.json"
+            if all(nm in k for nm in names):  # counters collected for this build's kernels
+                traffic = sum(k[nm]["hbm_bytes_per_launch"] for nm in names)
+                traffic_src = "profiles/r01_pmc_traffic.json"
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -171,6 +172,7 @@ def main():
                           "%d pass kernels (hipEvents on the launch stream); traffic = PMC HBM bytes of the "
                           "same launches" % plan.hbm_passes,
             "algorithmic_bytes_per_transform": 2 * n * 8, "passes": plan.hbm_passes,
+            "pass_stages": [stages for _, _, stages in plan.passes],
             "pass_ms": [float(v) for v in per_pass], "dominant_pass": dom,
             # each pass kernel reads and writes every coefficient once: its own stream rate
             "pass_stream_GBs": [alg_bytes / (float(v) * 1e-3) / 1e9 for v in per_pass],

@@ -103,7 +103,8 @@ int ntt_plan_generate_twiddles(ntt_plan_t plan, int kind, uint64_t g);
 int ntt_plan_get_twiddles(ntt_plan_t plan, int inverse, void *host_T);
 
 /* plan introspection (for harnesses): 0 logn, 1 word_bytes, 2 device,
- * 3 number of HBM passes of one forward transform, 4 has-inverse-table */
+ * 3 number of HBM passes of one forward transform, 4 has-inverse-table,
+ * 32 + i: stages in pass i, 64 + i: first stage of pass i (pass 0 is the contiguous one) */
 int64_t ntt_plan_info(ntt_plan_t plan, int what);
 
 /* ---- transforms ------------------------------------------------------------

@@ -246,7 +246,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     pl->d_fused_ctl = nullptr;
     pl->fused_max_batch = 0;
     if (const char *e = getenv("NTT_FUSED")) pl->fused = atoi(e);
-    pl->passes = plan_passes(logn);
+    pl->passes = plan_passes(logn, word_bytes);
     if (const char *e = getenv("NTT_PLAN_SPLIT")) {  // experiment knob: "8,6,6" = CONTIG 8 stages + two 6-stage column passes
         std::vector<PassDesc> v;
         int s0 = 0;
@@ -409,6 +409,8 @@ int64_t ntt_plan_info(ntt_plan_t pl, int what) {
         case 5: return pl->d_fused_ctl ? 1 : 0;
         default: break;
     }
+    if (what >= 32 && what < 32 + (int) pl->passes.size()) return pl->passes[what - 32].log_m;
+    if (what >= 64 && what < 64 + (int) pl->passes.size()) return pl->passes[what - 64].s0;
     if (what >= 16 && what < 16 + 12 && pl->d_fused_ctl) {  // diagnostics: words of the last fused launch (blocking)
         uint32_t w[12];
         DeviceGuard g(pl->device);

@@ -56,11 +56,24 @@ inline uint64_t bitrev(uint64_t x, int bits) {
 }
 
 // Split logn stages into HBM passes: one contiguous pass of <= 12 stages (tile =
-// 4096 words in LDS) followed by column passes of 4..8 stages (256 rows x 16 columns).
-inline std::vector<PassDesc> plan_passes(int n) {
+// 4096 words in LDS) followed by column passes of 4..8 stages (<= 256 rows x one 128-byte segment).
+// Always the fewest passes; for the two-pass sizes the split is the measured optimum
+// (tools/split_sweep.py, profiles/r01_g_split_sweep.jsonl): a pass costs about max(VALU, memory) plus a
+// quarter of the smaller one; a light column pass (6-7 stages) streams at the device's copy rate, and an
+// 8-stage first pass is the sweet spot of both CONTIG kernels.
+inline std::vector<PassDesc> plan_passes(int n, int word_bytes = 8) {
     std::vector<PassDesc> v;
     if (n <= MAX_CONTIG_LOG_M) {
         v.push_back({true, 0, n});
+        return v;
+    }
+    if (n <= MAX_CONTIG_LOG_M + MAX_COL_LOG_M) {
+        //                              n = 13  14  15  16  17  18  19  20
+        static const int first_w8[8] = {7, 8, 8, 8, 9, 10, 11, 12};  // (9,7) wins N = 2^16 at batch 8192 but loses at 4096
+        static const int first_w4[8] = {8, 8, 8, 8, 10, 10, 12, 12};
+        const int first = (word_bytes == 8 ? first_w8 : first_w4)[n - MAX_CONTIG_LOG_M - 1];
+        v.push_back({true, 0, first});
+        v.push_back({false, first, n - first});
         return v;
     }
     const int extra = (n - MAX_CONTIG_LOG_M + MAX_COL_LOG_M - 1) / MAX_COL_LOG_M;

@@ -99,6 +99,13 @@ class NTTPlan:
         return int(_lib.lib().ntt_plan_info(self._h, 3))
 
     @property
+    def passes(self) -> list[tuple[str, int, int]]:
+        """[(kind, first stage, stages)] of one forward transform; kind is 'contig' for pass 0, 'col' after."""
+        L = _lib.lib()
+        return [("contig" if i == 0 else "col", int(L.ntt_plan_info(self._h, 64 + i)), int(L.ntt_plan_info(self._h, 32 + i)))
+                for i in range(self.hbm_passes)]
+
+    @property
     def has_inverse(self) -> bool:
         return bool(_lib.lib().ntt_plan_info(self._h, 4))
 

@@ -184,7 +184,7 @@ int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, con
     }
     std::vector<PassDesc> passes;
     if (passes_override == 0) {
-        passes = plan_passes(logn);
+        passes = plan_passes(logn, word_bytes);
     } else {
         int s0 = 0;
         bool first = true;
@@ -252,7 +252,7 @@ int emu_forward_product(int word_bytes, int logn, uint64_t p, const void *T_plai
     e.batch = batch;
     e.target_wgs = target_wgs;
     e.tw = word_bytes == 4 ? (const void *) t32.data() : (const void *) t64.data();
-    const std::vector<PassDesc> passes = plan_passes(logn);
+    const std::vector<PassDesc> passes = plan_passes(logn, word_bytes);
     const void *cur = in;
     for (size_t i = 0; i < passes.size(); i++) {
         e.in = cur;
@@ -269,8 +269,8 @@ int emu_forward_product(int word_bytes, int logn, uint64_t p, const void *T_plai
 }
 
 // the planner's split, for tests: writes up to 8 (contig, s0, log_m) triples
-int emu_plan(int logn, int *out_triples) {
-    auto v = plan_passes(logn);
+int emu_plan(int logn, int word_bytes, int *out_triples) {
+    auto v = plan_passes(logn, word_bytes);
     for (size_t i = 0; i < v.size() && i < 8; i++) {
         out_triples[3 * i] = v[i].contig;
         out_triples[3 * i + 1] = v[i].s0;

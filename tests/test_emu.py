@@ -67,16 +67,19 @@ def test_every_tile_shape(oracle, ov):
 
 def test_planner_covers_all_sizes():
     tri = (C.c_int * 24)()
-    for logn in range(1, 29):
-        k = emu_lib.lib().emu_plan(logn, tri)
-        passes = [(tri[3 * i], tri[3 * i + 1], tri[3 * i + 2]) for i in range(k)]
-        assert passes[0][0] == 1 and passes[0][1] == 0 and 1 <= passes[0][2] <= 12
-        s0 = passes[0][2]
-        for contig, s, m in passes[1:]:
-            assert contig == 0 and s == s0 and 4 <= m <= 8
-            s0 += m
-        assert s0 == logn
-        assert k == (1 if logn <= 12 else 1 + -(-(logn - 12) // 8))  # fewest HBM passes
+    for wb in (4, 8):
+        for logn in range(1, 29):
+            k = emu_lib.lib().emu_plan(logn, wb, tri)
+            passes = [(tri[3 * i], tri[3 * i + 1], tri[3 * i + 2]) for i in range(k)]
+            assert passes[0][0] == 1 and passes[0][1] == 0 and 1 <= passes[0][2] <= 12
+            s0 = passes[0][2]
+            if k > 1:
+                assert s0 >= (4 if wb == 8 else 5)  # column tiles are 16 / 32 words wide
+            for contig, s, m in passes[1:]:
+                assert contig == 0 and s == s0 and 4 <= m <= 8
+                s0 += m
+            assert s0 == logn
+            assert k == (1 if logn <= 12 else 1 + -(-(logn - 12) // 8))  # fewest HBM passes
 
 
 def test_field_arithmetic_edges():

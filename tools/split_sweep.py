@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Experiment: per-pass time of alternative stage splits (NTT_PLAN_SPLIT) at a fixed 4 GiB of Goldilocks
-coefficients.  usage: split_sweep.py logn split [split ...]   e.g.  split_sweep.py 20 12,8 8,6,6 7,7,6"""
+"""Experiment: per-pass time of alternative stage splits (NTT_PLAN_SPLIT) at a fixed 4 GiB of coefficients
+(Goldilocks; NTT_SWEEP_WB=4 for 4-byte words).  usage: split_sweep.py logn split [split ...]
+e.g.  split_sweep.py 20 12,8 8,6,6 7,7,6"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,15 +9,19 @@ import torch
 from ntt_aie_amd import NTTPlan
 
 GOLD = 0xFFFFFFFF00000001
+WB = int(os.environ.get("NTT_SWEEP_WB", "8"))
+P, G = (GOLD, 7) if WB == 8 else (3221225473, 5)
 logn = int(sys.argv[1])
-batch = (1 << 29) >> logn
+batch = (1 << (32 - (3 if WB == 8 else 2))) >> logn
 g = torch.Generator(device="cuda:0").manual_seed(1)
-x = torch.randint(0, 1 << 62, (batch, 1 << logn), dtype=torch.int64, device="cuda:0", generator=g)
+x = torch.randint(0, 1 << 62 if WB == 8 else P, (batch, 1 << logn), dtype=torch.int64, device="cuda:0", generator=g)
+if WB == 4:
+    x = x.to(torch.int32)
 y = torch.empty_like(x)
 for split in sys.argv[2:]:
     os.environ["NTT_PLAN_SPLIT"] = split
-    plan = NTTPlan(logn, GOLD, 8, 0)
-    plan.generate_twiddles(1, 7)
+    plan = NTTPlan(logn, P, WB, 0)
+    plan.generate_twiddles(1, G)
     for _ in range(3):
         plan.forward(x, y)
     best = None
@@ -24,5 +29,5 @@ for split in sys.argv[2:]:
         ms = plan.forward_profile(x, y)
         if best is None or sum(ms) < sum(best):
             best = ms
-    print(json.dumps({"logn": logn, "batch": batch, "split": split, "passes": plan.hbm_passes,
+    print(json.dumps({"wb": WB, "logn": logn, "batch": batch, "split": split, "passes": plan.hbm_passes,
                       "pass_ms": [round(m, 3) for m in best], "total_ms": round(sum(best), 3)}), flush=True)
