@@ -163,8 +163,14 @@ constexpr int contig_preload_mask(int log_m, int word_bytes, int log_e = 4) {
     return log_m == 12 ? NTT_CONTIG12_MASK : 0x0;
 }
 
+#ifndef NTT_COL_E8
+#define NTT_COL_E8 0  // experiment knob: 8-stage Goldilocks column pass as radix-8 rounds in 512-thread workgroups
+#endif
 template <class F, int LOG_M, bool INV>
-using ColPassCfg = PassCfg<F, LOG_M, col_log_c(sizeof(typename F::W)), false, INV, 0xF, 4, col_log_nt(sizeof(typename F::W))>;
+using ColPassCfg = std::conditional_t<
+    NTT_COL_E8 && sizeof(typename F::W) == 8 && LOG_M == 8,
+    PassCfg<F, LOG_M, 4, false, INV, 0xF, 3, 9>,
+    PassCfg<F, LOG_M, col_log_c(sizeof(typename F::W)), false, INV, 0xF, 4, col_log_nt(sizeof(typename F::W))>>;
 
 template <class Cfg>
 struct PassArgs {
@@ -603,7 +609,18 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
                 constexpr int eA = ((k0 >> t) << (t + 1)) | (k0 & ((1 << t) - 1));
                 constexpr int eB = ((k1 >> t) << (t + 1)) | (k1 & ((1 << t) - 1));
                 const W TA = c.tw[r][off + (eA >> (t + 1))], TB = c.tw[r][off + (eB >> (t + 1))];
-                if constexpr (tw_uniform<Cfg, r>()) {
+                if constexpr (!Cfg::CONTIG && Cfg::LOG_E < 4) {  // experimental light column kernel: scratch at v[56:79]
+                    if constexpr (tw_uniform<Cfg, r>()) {
+                        if constexpr (!Cfg::INV) gl_fwd2_s_lo2(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
+                        else gl_inv2_s_lo2(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
+                    } else {
+                        if constexpr (!Cfg::INV) gl_fwd2_v_lo2(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
+                        else gl_inv2_v_lo2(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
+                    }
+                } else if constexpr (tw_uniform<Cfg, r>() && Cfg::LOG_E < 4) {
+                    if constexpr (!Cfg::INV) gl_fwd2_s_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
+                    else gl_inv2_s_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
+                } else if constexpr (tw_uniform<Cfg, r>()) {
                     if constexpr (!Cfg::INV) gl_fwd2_s(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
                     else gl_inv2_s(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
                 } else if constexpr (Cfg::LOG_E < 4) {  // light kernels: asm scratch lives lower (v[76:95])

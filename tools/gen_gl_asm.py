@@ -301,9 +301,11 @@ def main():
             out.append("")
             print(f"{kind} x2 tw={tw}: {n} instructions, {nops} nops", file=sys.stderr)
         if kind != "mul":
-            txt, n, nops = emit(kind, 2, "v", vbase=72, suffix="_lo")  # for the radix-8 (light) kernels
-            out.append(txt)
-            out.append("")
+            for tw in ("v", "s"):  # for the radix-8 (light) kernels: scratch lives lower
+                for vb, sfx in ((72, "_lo"), (56, "_lo2")):
+                    txt, n, nops = emit(kind, 2, tw, vbase=vb, suffix=sfx)
+                    out.append(txt)
+                    out.append("")
     for kind in ("fwd32", "inv32"):
         for small in (True, False):
             txt, n, nops = emit32(kind, 4, small)
