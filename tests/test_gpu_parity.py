@@ -584,3 +584,32 @@ def test_roctx_ranges_under_rocprofv3(tmp_path):
     for name in ("ntt_forward", "fwd pass contig stages 0-%d" % (m0 - 1), "fwd pass column stages %d-%d" % (s1, s1 + m1 - 1),
                  "ntt_inverse", "inv pass column stages %d-%d" % (s1, s1 + m1 - 1), "inv pass contig stages 0-%d" % (m0 - 1)):
         assert name in text, name
+
+
+def test_randomized_differential(eng, oracle):
+    """Seeded random sweep over moduli (tiny, around 2^31, up to 2^32-1, composite odd, Goldilocks), sizes, batches,
+    layouts, in-place / out-of-place and both directions: every output word equals the oracle's.  The table rule is
+    make_roots with its integer division (src/test.cpp:28), so the moduli need not be NTT-friendly."""
+    moduli4 = [3, 5, 7, 3329, 12289, 40961, 65537, 786433, 8380417, 469762049, 998244353, 2013265921, 2147483647,
+               2147483649, 2147483659, 3221225473, 4293918721, 4294967291, 4294967295]
+    rng = np.random.default_rng(20261003)
+    for case in range(72):
+        wb = 8 if case % 6 == 5 else 4
+        p = GOLD if wb == 8 else int(moduli4[int(rng.integers(len(moduli4)))])
+        g = int(rng.integers(2, 50))
+        logn = int(rng.integers(1, 16))
+        n = 1 << logn
+        batch = int(rng.integers(1, 38))
+        layout = int(rng.integers(2)) if logn >= 4 else 0
+        dt = np.uint32 if wb == 4 else np.uint64
+        T = oracle.make_roots(n, p, g, wb)
+        pl = _plan(eng, logn, p, wb, T)
+        a = _rand(batch, n, p, dt, case)
+        want = oracle.ntt(a, T, p, nthreads=4)
+        d = eng.to_device(a, "cuda:0")
+        f = pl.forward(d, d if case % 2 else None, layout=layout)  # odd cases transform in place
+        got = eng.to_host(f)
+        assert np.array_equal(got, oracle.block16(want) if layout else want), (case, wb, p, g, logn, batch, layout)
+        if pl.has_inverse:
+            back = pl.inverse(f, f if case % 3 == 0 else None, layout=layout)
+            assert np.array_equal(eng.to_host(back), a), (case, wb, p, g, logn, batch, layout)
