@@ -613,3 +613,27 @@ def test_randomized_differential(eng, oracle):
         if pl.has_inverse:
             back = pl.inverse(f, f if case % 3 == 0 else None, layout=layout)
             assert np.array_equal(eng.to_host(back), a), (case, wb, p, g, logn, batch, layout)
+
+
+def test_against_literal_reference_library(eng, oracle):
+    """HIP path vs the COMPILED LITERAL reference lines (oracle/_ref/libntt_ref.so: src/test.cpp:15-60, 69-71,
+    212-219 built by oracle/build_ref.sh; the prebuilt library travels to the GPU box), inside the literal code's
+    validity window p <= 46340: table, full network, intermediate stages (test_stage hook) and block order."""
+    if not oracle.have_ref():
+        pytest.skip("literal reference library not present on this box")
+    rng = np.random.default_rng(7)
+    for n, p, g in [(16, 3329, 3), (256, 3329, 3), (2048, 3329, 3), (4096, 12289, 11), (8192, 40961, 3), (1 << 14, 46337, 5)]:
+        logn = n.bit_length() - 1
+        Tr = oracle.ref_make_roots(n, p, g)
+        pl = eng.NTTPlan(logn, p, 4, 0)
+        assert np.array_equal(pl.make_roots(g).astype(np.int64), Tr.astype(np.int64))
+        pl.set_twiddles(Tr.astype(np.uint32))
+        a = rng.integers(0, p, size=n, dtype=np.int64)
+        d = eng.to_device(a.astype(np.uint32)[None, :], "cuda:0")
+        want = oracle.ref_ntt(a.astype(np.int32), Tr, p, logn - 1)
+        assert np.array_equal(eng.to_host(pl.forward(d))[0].astype(np.int64), want.astype(np.int64)), (n, p)
+        blk = eng.to_host(pl.forward(d, layout=eng.LAYOUT_AIE_BLOCK16))[0]
+        assert np.array_equal(blk.astype(np.int32), oracle.ref_block_order(want)), (n, p)
+        for stage in {0, logn // 2}:
+            got = eng.to_host(pl.forward_stages(d, stage))[0]
+            assert np.array_equal(got.astype(np.int64), oracle.ref_ntt(a.astype(np.int32), Tr, p, stage).astype(np.int64))
