@@ -59,3 +59,14 @@ def test_product_has_no_oracle_dependency():
             if f.endswith((".py", ".h", ".hip", ".inc", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle_py" not in text and "ntt_oracle" not in text and "libntt_oracle" not in text, f
+
+
+def test_generated_instruction_streams_are_current(tmp_path):
+    """csrc/gl_asm.h is generated: the committed file must be what tools/gen_gl_asm.py emits today."""
+    import subprocess
+    import sys
+
+    out = tmp_path / "gl_asm.h"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_gl_asm.py"), str(out)],
+                          stderr=subprocess.DEVNULL)
+    assert out.read_text() == open(os.path.join(ROOT, "ntt_aie_amd", "csrc", "gl_asm.h")).read()
