@@ -41,6 +41,9 @@
 #ifndef NTT_COL_PREFETCH
 #define NTT_COL_PREFETCH 0  // experiment knob: register prefetch in the 8-stage column pass
 #endif
+#ifndef NTT_SETPRIO
+#define NTT_SETPRIO 1  // bit 0: raise the wave priority (s_setprio 3) while it issues its global loads (column pass -1.3 %); bit 1: stores (no gain)
+#endif
 #ifndef NTT_INV_PREFETCH
 #define NTT_INV_PREFETCH 0  // experiment knob: register prefetch in the inverse CONTIG radix-8 passes (measured: no gain)
 #endif
@@ -668,6 +671,17 @@ NTT_HD void phase_scale(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
     for (int e = 0; e < Cfg::E; ++e) c.x[e] = a.field.mul(c.x[e], a.scale);
 }
 
+NTT_HD void wave_prio(int level) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NTT_SETPRIO) {
+        if (level) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(0);
+    }
+#else
+    (void) level;
+#endif
+}
+
 // ---- the schedule (src/aie2.py:166-315, collapsed) ----------------------------
 // Exec supplies: each(fn) -- run fn(ctx) for this lane (GPU) or for all 256
 // contexts (host model); sync() -- workgroup barrier; lds() -- the tile.
@@ -697,7 +711,9 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         if constexpr (Cfg::DMA) {
             if (it == 0) ex.each([&](C &) { phase_dma_wait<Cfg, true>(); });
             else ex.each([&](C &) { phase_dma_wait<Cfg, false>(); });
+            wave_prio(NTT_SETPRIO & 1);
             if (group_valid(it + 1)) ex.each([&](C &c) { phase_dma_issue<Cfg>(c, a, ex.lds(), it + 1); });
+            wave_prio(0);
             ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, tile); });
         } else if constexpr (Cfg::REG_PREFETCH) {
             ex.each([&](C &c) {
@@ -706,7 +722,9 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             });
             if (group_valid(it + 1)) ex.each([&](C &c) { phase_load_direct<Cfg, FIRST, true>(c, a, it + 1); });
         } else if constexpr (Cfg::DIRECT_LOAD) {
+            wave_prio(NTT_SETPRIO & 1);
             ex.each([&](C &c) { phase_load_direct<Cfg, FIRST>(c, a, it); });
+            wave_prio(0);
         } else {
             ex.each([&](C &c) { phase_linear<Cfg, true>(c, a, tile, it); });
             ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
@@ -725,7 +743,9 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         });
         if constexpr (Cfg::INV) ex.each([&](C &c) { phase_scale<Cfg>(c, a); });
         if constexpr (Cfg::DIRECT_STORE) {
+            wave_prio(NTT_SETPRIO & 2);
             ex.each([&](C &c) { phase_store_direct<Cfg, LAST>(c, a, it); });
+            wave_prio(0);
         } else {
             ex.each([&](C &c) { phase_lds_write<Cfg, LAST>(c, tile); });
             ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
