@@ -42,7 +42,7 @@
 #define NTT_COL_PREFETCH 0  // experiment knob: register prefetch in the 8-stage column pass
 #endif
 #ifndef NTT_SETPRIO
-#define NTT_SETPRIO 1  // bit 0: raise the wave priority (s_setprio 3) while it issues its global loads (column pass -1.3 %); bit 1: stores (no gain)
+#define NTT_SETPRIO 1  // bit 0: raise the wave priority (s_setprio 3) while it issues its global loads (column pass -1.3 %); bit 1: stores (no gain); bit 2: across an LDS exchange
 #endif
 #ifndef NTT_INV_PREFETCH
 #define NTT_INV_PREFETCH 0  // experiment knob: register prefetch in the inverse CONTIG radix-8 passes (measured: no gain)
@@ -736,9 +736,11 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.each([&](C &c) { phase_compute<Cfg, r>(c, a); });
             if constexpr (k < R - 1) {
                 constexpr int rn = Cfg::INV ? r - 1 : r + 1;
+                wave_prio(NTT_SETPRIO & 4);
                 ex.each([&](C &c) { phase_lds_write<Cfg, r>(c, tile); });
                 ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
                 ex.each([&](C &c) { phase_lds_read<Cfg, rn>(c, tile); });
+                if (NTT_SETPRIO & 4) wave_prio(0);
             }
         });
         if constexpr (Cfg::INV) ex.each([&](C &c) { phase_scale<Cfg>(c, a); });
