@@ -44,6 +44,9 @@
 #ifndef NTT_SETPRIO
 #define NTT_SETPRIO 1  // bit 0: raise the wave priority (s_setprio 3) while it issues its global loads (column pass -1.3 %); bit 1: stores (no gain); bit 2: across an LDS exchange
 #endif
+#ifndef NTT_LATE_SYNC
+#define NTT_LATE_SYNC 0  // experiment knob: end-of-iteration barrier moved to before the next iteration's first LDS write (measured: column pass +2 %, worse)
+#endif
 #ifndef NTT_INV_PREFETCH
 #define NTT_INV_PREFETCH 0  // experiment knob: register prefetch in the inverse CONTIG radix-8 passes (measured: no gain)
 #endif
@@ -692,6 +695,11 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     constexpr int FIRST = Cfg::INV ? R - 1 : 0;
     constexpr int LAST = Cfg::INV ? 0 : R - 1;
     constexpr bool ANY_LDS = R > 1 || !Cfg::DIRECT_LOAD || !Cfg::DIRECT_STORE;
+    // The barrier that keeps the next iteration from rewriting the tile while a slower wave still reads it is
+    // only needed before that iteration's FIRST LDS WRITE.  When the iteration starts with direct global loads
+    // and a register round, it is placed there (after the round) instead of at the end of the iteration: a wave
+    // issues its next loads right behind its stores and computes a round while the others catch up.
+    constexpr bool LATE_SYNC = NTT_LATE_SYNC && Cfg::DIRECT_LOAD && R > 1 && !Cfg::DMA && !Cfg::REG_PREFETCH;
     ex.init(a);
     auto group_valid = [&](int it) {  // uniform: does polynomial group `it` of this workgroup exist
         return it < a.ppw && (((uint64_t) ex.pg_base() + (uint64_t) it * (uint32_t) a.pg_stride) << a.log_up) < a.batch;
@@ -736,6 +744,9 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.each([&](C &c) { phase_compute<Cfg, r>(c, a); });
             if constexpr (k < R - 1) {
                 constexpr int rn = Cfg::INV ? r - 1 : r + 1;
+                if constexpr (LATE_SYNC && k == 0) {
+                    if (it > 0) ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});  // previous iteration's tile reads are done
+                }
                 wave_prio(NTT_SETPRIO & 4);
                 ex.each([&](C &c) { phase_lds_write<Cfg, r>(c, tile); });
                 ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
@@ -755,7 +766,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         }
         ex.iter_done(it);  // fused schedule: publish the previous polynomial's tile
         ++completed;
-        if constexpr (ANY_LDS) {
+        if constexpr (ANY_LDS && !LATE_SYNC) {
             ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});  // next iteration rewrites the tile
         }
     }
