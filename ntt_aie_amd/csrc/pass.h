@@ -156,8 +156,11 @@ constexpr int contig_log_nt(int log_m, int word_bytes, bool last_pass) {
 // Column tile: 2^LOG_C consecutive words per row segment = one 128-byte line either way:
 // 16 columns of 8-byte words in 256-thread workgroups, 32 columns of 4-byte words in 512-thread ones
 // (with 16 columns the 4-byte passes moved 64-byte half lines: 3.9 ms against 1.8 ms per 4 GiB).
-constexpr int col_log_c(int word_bytes) { return word_bytes == 8 ? 4 : 5; }
-constexpr int col_log_nt(int word_bytes) { return word_bytes == 8 ? 8 : 9; }
+#ifndef NTT_COL_GL_LOG_C
+#define NTT_COL_GL_LOG_C 4  // experiment knob: 5 = 256-byte row segments of 8-byte words in 512-thread workgroups
+#endif
+constexpr int col_log_c(int word_bytes) { return word_bytes == 8 ? NTT_COL_GL_LOG_C : 5; }
+constexpr int col_log_nt(int word_bytes) { return word_bytes == 8 ? 4 + NTT_COL_GL_LOG_C : 9; }
 
 constexpr int contig_preload_mask(int log_m, int word_bytes, int log_e = 4) {
     if (log_e < 4) return 0xF;
