@@ -590,8 +590,10 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
         constexpr int off = Cfg::E - (Cfg::E >> t);
 #if defined(__HIP_DEVICE_COMPILE__)
         if constexpr (std::is_same<typename Cfg::F, FieldM32>::value && Cfg::E >= 8) {
-            // four independent butterflies per statement; p < 2^31 takes the carry-free v_min_u32 form
-            const bool small_p = f.p < 0x80000000u;  // kernel argument: wave-uniform branch
+            // four independent butterflies per statement.  p < 2^30: values stay in [0, 2p) between butterflies,
+            // rounds and passes (10 / 11 instructions, phase_canon() at the end of the transform); p < 2^31:
+            // canonical values, carry-free v_min_u32 corrections (12); otherwise carry / borrow selects.
+            const int mode = f.p < 0x40000000u ? 0 : (f.p < 0x80000000u ? 1 : 2);  // kernel argument: wave-uniform branch
             static_for<0, Cfg::E / 8>([&](auto pp) {
                 constexpr int k0 = 4 * decltype(pp)::value;
                 constexpr int e0 = (((k0 + 0) >> t) << (t + 1)) | ((k0 + 0) & ((1 << t) - 1));
@@ -601,7 +603,10 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
                 constexpr int S = 1 << t;
                 const W T0 = c.tw[r][off + (e0 >> (t + 1))], T1 = c.tw[r][off + (e1 >> (t + 1))];
                 const W T2 = c.tw[r][off + (e2 >> (t + 1))], T3 = c.tw[r][off + (e3 >> (t + 1))];
-                if (small_p) {
+                if (mode == 0) {
+                    if constexpr (!Cfg::INV) m32_fwd4_lazy(c.x[e0], c.x[e0 | S], T0, c.x[e1], c.x[e1 | S], T1, c.x[e2], c.x[e2 | S], T2, c.x[e3], c.x[e3 | S], T3, f.p, f.pinv, 2u * f.p);
+                    else m32_inv4_lazy(c.x[e0], c.x[e0 | S], T0, c.x[e1], c.x[e1 | S], T1, c.x[e2], c.x[e2 | S], T2, c.x[e3], c.x[e3 | S], T3, f.p, f.pinv, 2u * f.p);
+                } else if (mode == 1) {
                     if constexpr (!Cfg::INV) m32_fwd4_small(c.x[e0], c.x[e0 | S], T0, c.x[e1], c.x[e1 | S], T1, c.x[e2], c.x[e2 | S], T2, c.x[e3], c.x[e3 | S], T3, f.p, f.pinv);
                     else m32_inv4_small(c.x[e0], c.x[e0 | S], T0, c.x[e1], c.x[e1 | S], T1, c.x[e2], c.x[e2 | S], T2, c.x[e3], c.x[e3 | S], T3, f.p, f.pinv);
                 } else {
@@ -675,6 +680,22 @@ NTT_HD void phase_scale(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
 #endif
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) c.x[e] = a.field.mul(c.x[e], a.scale);
+}
+
+// Lazy 4-byte-word arithmetic (p < 2^30) leaves values in [0, 2p): bring them to [0, p) once, in the pass that
+// finishes the transform (the scaled inverse already ends with a canonical product).  On canonical input the
+// subtraction wraps and the minimum is the input itself, so the host model may run it unconditionally.
+template <class Cfg>
+NTT_HD void phase_canon(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
+    if constexpr (std::is_same<typename Cfg::F, FieldM32>::value && Cfg::E >= 8) {
+        const bool last = Cfg::INV ? Cfg::CONTIG : (a.s0 + Cfg::LOG_M == a.n);
+        if (a.field.p >= 0x40000000u || !last || (Cfg::INV && a.do_scale)) return;
+#pragma unroll
+        for (int e = 0; e < Cfg::E; ++e) {
+            const uint32_t d = c.x[e] - a.field.p;
+            c.x[e] = d < c.x[e] ? d : c.x[e];
+        }
+    }
 }
 
 NTT_HD void wave_prio(int level) {
@@ -758,6 +779,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             }
         });
         if constexpr (Cfg::INV) ex.each([&](C &c) { phase_scale<Cfg>(c, a); });
+        ex.each([&](C &c) { phase_canon<Cfg>(c, a); });
         if constexpr (Cfg::DIRECT_STORE) {
             wave_prio(NTT_SETPRIO & 2);
             ex.each([&](C &c) { phase_store_direct<Cfg, LAST>(c, a, it); });

@@ -637,3 +637,29 @@ def test_against_literal_reference_library(eng, oracle):
         for stage in {0, logn // 2}:
             got = eng.to_host(pl.forward_stages(d, stage))[0]
             assert np.array_equal(got.astype(np.int64), oracle.ref_ntt(a.astype(np.int32), Tr, p, stage).astype(np.int64))
+
+
+def test_lazy_range_edges_small_moduli(eng, oracle):
+    """p < 2^30 runs the lazy butterflies (values in [0, 2p) between stages, canonicalised once at the end):
+    extreme residues and extreme twiddles at moduli on both sides of the 2^30 and 2^31 switch points, single- and
+    multi-pass sizes, forward, scaled and unscaled inverse -- word-exact against the oracle."""
+    for p in (3, 5, 3329, 12289, 1073741789, 1073741823, 1073741825, 1073741827, 2147483647, 2147483649):
+        for logn in (3, 5, 8, 12, 13):
+            n = 1 << logn
+            rng = np.random.default_rng(p % 1000 + logn)
+            tables = [np.full(n, p - 1, dtype=np.uint32), oracle.make_roots(n, p, 2, 4),
+                      (rng.integers(1, p, size=n, dtype=np.int64)).astype(np.uint32)]
+            rows = [np.full(n, p - 1), np.zeros(n), np.tile([p - 1, 0], n // 2), np.tile([0, p - 1], n // 2),
+                    rng.integers(0, p, size=n), np.full(n, p // 2), np.full(n, 1)]
+            a = np.stack(rows).astype(np.uint32)
+            for T in tables:
+                pl = _plan(eng, logn, p, 4, T)
+                want = oracle.ntt(a, T, p)
+                d = eng.to_device(a, "cuda:0")
+                f = pl.forward(d)
+                assert np.array_equal(eng.to_host(f), want), (p, logn)
+                assert pl.count_noncanonical(f) == 0
+                if pl.has_inverse:
+                    assert np.array_equal(eng.to_host(pl.inverse(f)), a), (p, logn)
+                    un = eng.to_host(pl.inverse(f, scale=False))  # N * a mod p, canonical
+                    assert np.array_equal(un, ((a.astype(np.uint64) * np.uint64(n % p)) % np.uint64(p)).astype(np.uint32)), (p, logn)

@@ -110,11 +110,16 @@ def butterfly(kind, b, vbase=104):
     return ins
 
 
-def butterfly32(kind, b, small, vbase=None):
+def butterfly32(kind, b, mode, vbase=None):
     """4-byte-word Montgomery butterfly `b` (R = 2^32, twiddle in Montgomery form).
-    small = True: p < 2^31, conditional corrections by v_min_u32 (no carries, no SGPRs);
-    small = False: any odd p < 2^32, carries in SGPR pairs.  Operands: x y t (compiler),
-    temporaries a b c, scalars %[p] %[pinv]; the 64-bit product lives in a fixed VGPR pair."""
+    mode "lazy":  p < 2^30, values kept in [0, 2p) (Harvey): no correction after the product, one
+                  v_min_u32 per sum; 10 (forward) / 11 (inverse) instructions.  Callers canonicalise
+                  once at the end of the transform.
+    mode "small": p < 2^31, canonical values, conditional corrections by v_min_u32 (12 instructions);
+    mode "any":   any odd p < 2^32, carries in SGPR pairs.
+    Operands: x y t (compiler), temporaries a b c, scalars %[p] %[pinv] (%[p2] = 2p when lazy); the
+    64-bit product lives in a fixed VGPR pair."""
+    small = mode == "small"
     L = (f"v{vbase + 2 * b}", f"v{vbase + 2 * b + 1}")
     LP = f"v[{vbase + 2 * b}:{vbase + 2 * b + 1}]"
     sa, sb = f"s[{84 + 4 * b}:{85 + 4 * b}]", f"s[{86 + 4 * b}:{87 + 4 * b}]"
@@ -123,7 +128,7 @@ def butterfly32(kind, b, small, vbase=None):
         return f"%[{name}{b}]"
 
     x, y, t, ta, tb, tc = o("x_"), o("y_"), o("t_"), o("a_"), o("b_"), o("c_")
-    P, PI = "%[p]", "%[pinv]"
+    P, PI, P2 = "%[p]", "%[pinv]", "%[p2]"
     ins = []
 
     def add(u, v, out):  # out = (u + v) mod p ; clobbers ta, tb
@@ -153,6 +158,32 @@ def butterfly32(kind, b, small, vbase=None):
         ins.append(Ins(f"v_mul_hi_u32 {t1}, {t1}, {P}", [t1], [t1]))
         sub(L[1], t1, out, t2)
 
+    # ---- lazy forms: every value in [0, 2p), 4p < 2^32 ----
+    def lazy_add(u, v, out):  # out = u + v reduced to [0, 2p) ; clobbers ta, tb
+        ins.append(Ins(f"v_add_u32 {ta}, {u}, {v}", [u, v], [ta]))            # < 4p
+        ins.append(Ins(f"v_subrev_u32 {tb}, {P2}, {ta}", [ta], [tb]))         # wraps (huge) when ta < 2p
+        ins.append(Ins(f"v_min_u32 {out}, {ta}, {tb}", [ta, tb], [out]))
+
+    def lazy_mul(m, out, t1):  # out = m * T * 2^-32 + p in (0, 2p), any m < 2^32 with m * p < 2^62 ; clobbers t1
+        ins.append(Ins(f"v_mad_u64_u32 {LP}, vcc, {m}, {t}, 0", [m, t], [L[0], L[1], "vcc"]))
+        ins.append(Ins(f"v_mul_lo_u32 {t1}, {L[0]}, {PI}", [L[0]], [t1]))
+        ins.append(Ins(f"v_mul_hi_u32 {t1}, {t1}, {P}", [t1], [t1]))
+        ins.append(Ins(f"v_sub_u32 {out}, {L[1]}, {t1}", [L[1], t1], [out]))    # in (-p, p)
+        ins.append(Ins(f"v_add_u32 {out}, {P}, {out}", [out], [out]))           # in (0, 2p)
+
+    if mode == "lazy":
+        if kind == "fwd32":    # x' = x + y ; y' = (x - y + 2p) * T
+            ins.append(Ins(f"v_sub_u32 {tc}, {x}, {y}", [x, y], [tc]))
+            ins.append(Ins(f"v_add_u32 {tc}, {P2}, {tc}", [tc], [tc]))          # in (0, 4p)
+            lazy_add(x, y, x)
+            lazy_mul(tc, y, ta)
+        else:                  # w = y * T ; x' = x + w ; y' = x - w
+            lazy_mul(y, tc, ta)
+            ins.append(Ins(f"v_sub_u32 {y}, {x}, {tc}", [x, tc], [y]))          # wraps (huge) when x < w
+            ins.append(Ins(f"v_add_u32 {tb}, {P2}, {y}", [y], [tb]))            # then this one is x - w + 2p
+            ins.append(Ins(f"v_min_u32 {y}, {y}, {tb}", [y, tb], [y]))
+            lazy_add(x, tc, x)
+        return ins
     if kind == "fwd32":    # x' = x + y ; y' = (x - y) * T
         sub(x, y, tc, ta)
         add(x, y, x)
@@ -164,14 +195,16 @@ def butterfly32(kind, b, small, vbase=None):
     return ins
 
 
-def emit32(kind, nb, small, vbase=M32_VBASE):
-    lists = [butterfly32(kind, b, small, vbase) for b in range(nb)]
+def emit32(kind, nb, mode, vbase=M32_VBASE):
+    lists = [butterfly32(kind, b, mode, vbase) for b in range(nb)]
     lines = schedule(lists)
     nops = sum(1 for l in lines if l.startswith("s_nop"))
-    name = f"m32_{kind[:3]}{nb}_{'small' if small else 'any'}"
+    name = f"m32_{kind[:3]}{nb}_{mode}"
+    what = {"lazy": "p < 2^30, values in [0, 2p)", "small": "p < 2^31", "any": "any odd p < 2^32"}[mode]
     args = ", ".join(f"uint32_t &x{b}, uint32_t &y{b}, uint32_t t{b}" for b in range(nb))
-    src = [f"// {kind} x{nb} ({'p < 2^31' if small else 'any odd p < 2^32'}): {len(lines)} instructions, {nops} s_nop",
-           f"__device__ __forceinline__ void {name}({args}, uint32_t p, uint32_t pinv) {{"]
+    extra = ", uint32_t p2" if mode == "lazy" else ""
+    src = [f"// {kind} x{nb} ({what}): {len(lines)} instructions, {nops} s_nop",
+           f"__device__ __forceinline__ void {name}({args}, uint32_t p, uint32_t pinv{extra}) {{"]
     for b in range(nb):
         src.append(f"    uint32_t a_{b}, b_{b}, c_{b};")
     src.append("    asm volatile(")
@@ -183,8 +216,10 @@ def emit32(kind, nb, small, vbase=M32_VBASE):
         outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("a_", "b_", "c_")]
         ins_ += [f'[t_{b}] "v"(t{b})']
     ins_ += ['[p] "s"(p)', '[pinv] "s"(pinv)']
+    if mode == "lazy":
+        ins_ += ['[p2] "s"(p2)']
     clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 2 * nb)]
-    if not small:
+    if mode == "any":
         clob += [f'"s{r}"' for r in range(84, 84 + 4 * nb)]
     src.append("        : " + ", ".join(outs))
     src.append("        : " + ", ".join(ins_))
@@ -307,11 +342,11 @@ def main():
                     out.append(txt)
                     out.append("")
     for kind in ("fwd32", "inv32"):
-        for small in (True, False):
-            txt, n, nops = emit32(kind, 4, small)
+        for mode in ("lazy", "small", "any"):
+            txt, n, nops = emit32(kind, 4, mode)
             out.append(txt)
             out.append("")
-            print(f"{kind} x4 small={small}: {n} instructions, {nops} nops", file=sys.stderr)
+            print(f"{kind} x4 {mode}: {n} instructions, {nops} nops", file=sys.stderr)
     out += ["}  // namespace ntt", "#endif"]
     open(sys.argv[1] if len(sys.argv) > 1 else "ntt_aie_amd/csrc/gl_asm.h", "w").write("\n".join(out) + "\n")
 
