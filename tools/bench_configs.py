@@ -44,6 +44,8 @@ if __name__ == "__main__":
     run("cfg2: N=2^12, 32-bit prime 3221225473, batch 1024", 12, 3221225473, 5, 4, 1024)
     run("cfg2b: N=2^12, p=12289 (literal-oracle window), batch 1024", 12, 12289, 11, 4, 1024)
     run("cfg2c: N=2^12, 32-bit prime, batch 65536 (saturating)", 12, 3221225473, 5, 4, 65536)
+    run("cfg2d: N=2^12, p=998244353 (< 2^30: lazy butterflies), batch 65536", 12, 998244353, 3, 4, 65536)
+    run("kyber-like: N=2^8, p=3329, batch 2^20", 8, 3329, 3, 4, 1 << 20)
     run("cfg3: N=2^16, Goldilocks, batch 4096, forward+inverse", 16, GOLD, 7, 8, 4096)
     run("cfg4: N=2^20, Goldilocks, batch 512, negacyclic polymul", 20, GOLD, 7, 8, 512, kind=2, polymul=True)
     run("ref: N=2^11, p=3329, batch 1 (the reference's own launch)", 11, 3329, 3, 4, 1)
