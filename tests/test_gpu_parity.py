@@ -378,7 +378,7 @@ def test_bench_json_contract():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
 
 
-@pytest.mark.parametrize("wb,p,g", [(8, GOLD, 7), (4, 3221225473, 5)])
+@pytest.mark.parametrize("wb,p,g", [(8, GOLD, 7), (4, 3221225473, 5), (4, 998244353, 3)])
 def test_three_pass_sizes(eng, oracle, wb, p, g):
     """N = 2^21 and 2^22: three HBM passes (CONTIG + two column passes)."""
     dt = np.uint32 if wb == 4 else np.uint64
