@@ -687,6 +687,17 @@ NTT_HD void phase_scale(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
 // subtraction wraps and the minimum is the input itself, so the host model may run it unconditionally.
 template <class Cfg>
 NTT_HD void phase_canon(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
+    if constexpr (std::is_same<typename Cfg::F, FieldGL>::value && Cfg::INV && Cfg::CONTIG && Cfg::E >= 4) {
+        // Goldilocks inverse (DIT) butterflies keep sums and differences as ANY 64-bit representative (their
+        // other operand is always a canonical product); the scaled inverse ends with a canonical product, the
+        // unscaled one is canonicalised here: x >= p  <=>  x + (2^32 - 1) carries, and the wrapped sum is x - p.
+        if (a.do_scale) return;
+#pragma unroll
+        for (int e = 0; e < Cfg::E; ++e) {
+            const uint64_t t = c.x[e] + 0xFFFFFFFFull;
+            c.x[e] = t < c.x[e] ? t : c.x[e];
+        }
+    }
     if constexpr (std::is_same<typename Cfg::F, FieldM32>::value && Cfg::E >= 8) {
         const bool last = Cfg::INV ? Cfg::CONTIG : (a.s0 + Cfg::LOG_M == a.n);
         if (a.field.p >= 0x40000000u || !last || (Cfg::INV && a.do_scale)) return;

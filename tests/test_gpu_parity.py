@@ -663,3 +663,28 @@ def test_lazy_range_edges_small_moduli(eng, oracle):
                     assert np.array_equal(eng.to_host(pl.inverse(f)), a), (p, logn)
                     un = eng.to_host(pl.inverse(f, scale=False))  # N * a mod p, canonical
                     assert np.array_equal(un, ((a.astype(np.uint64) * np.uint64(n % p)) % np.uint64(p)).astype(np.uint32)), (p, logn)
+
+
+def test_goldilocks_inverse_lazy_representatives(eng, oracle):
+    """The Goldilocks inverse butterflies carry sums as arbitrary 64-bit representatives; outputs must still be
+    canonical and exact: extreme residues / twiddles, scaled and unscaled inverse, single-, two- and three-pass sizes."""
+    p = GOLD
+    for logn in (2, 5, 12, 13, 16, 21):
+        n = 1 << logn
+        rng = np.random.default_rng(logn)
+        tables = [oracle.make_roots(n, p, 7, 8), np.full(n, p - 1, dtype=np.uint64)]
+        rows = [np.full(n, p - 1, dtype=np.uint64), np.zeros(n, dtype=np.uint64),
+                np.tile(np.array([p - 1, 0], dtype=np.uint64), n // 2), np.full(n, 0xFFFFFFFF, dtype=np.uint64),
+                np.full(n, 0xFFFFFFFF00000000, dtype=np.uint64), _rand(1, n, p, np.uint64, logn)[0]]
+        a = np.stack(rows)
+        for T in tables:
+            pl = _plan(eng, logn, p, 8, T)
+            y = oracle.ntt(a, T, p, nthreads=4)
+            d = eng.to_device(y, "cuda:0")
+            back = pl.inverse(d)
+            assert pl.count_noncanonical(back) == 0
+            assert np.array_equal(eng.to_host(back), a), logn
+            un = pl.inverse(d, scale=False)
+            assert pl.count_noncanonical(un) == 0
+            want = np.array([[(int(v) * n) % p for v in row] for row in a[:, :64]], dtype=np.uint64)
+            assert np.array_equal(eng.to_host(un)[:, :64], want), logn

@@ -77,6 +77,16 @@ def butterfly(kind, b, vbase=104):
         ins.append(Ins(f"s_andn2_b64 {se}, {se}, {sf}", [se, sf], [se], salu=True))
         ins.append(Ins(f"v_addc_co_u32 {out1}, {sf}, {Z[1]}, 0, {se}", [Z[1], se], [out1, sf]))
 
+    def lazy_add(a0, a1, b0, b1):
+        # a += b (mod p) where b is canonical and a is ANY 64-bit representative; the result is again any
+        # representative: sum, then + carry*(2^32-1), which cannot carry twice because b < p.  4 VALU + 1 SALU.
+        # (Inverse / DIT butterflies only: there one operand of every sum is a fresh product.)
+        ins.append(Ins(f"v_add_co_u32 {a0}, {se}, {a0}, {b0}", [a0, b0], [a0, se]))
+        ins.append(Ins(f"v_addc_co_u32 {a1}, {se}, {a1}, {b1}, {se}", [a1, b1, se], [a1, se]))
+        ins.append(Ins(f"v_subbrev_co_u32 {a0}, {sf}, 0, {a0}, {se}", [a0, se], [a0, sf]))
+        ins.append(Ins(f"s_andn2_b64 {se}, {se}, {sf}", [se, sf], [se], salu=True))
+        ins.append(Ins(f"v_addc_co_u32 {a1}, {sf}, {a1}, 0, {se}", [a1, se], [a1, sf]))
+
     def mul(m0, m1, r0, r1):
         # (m1:m0) * (t1:t0) * 2^-64 mod p, canonical; m may be any 64-bit value
         ins.append(Ins(f"v_mad_u64_u32 {P(L)}, vcc, {m0}, {t0}, 0", [m0, t0], [L[0], L[1], "vcc"]))
@@ -103,8 +113,8 @@ def butterfly(kind, b, vbase=104):
         mul(d0, d1, y0, y1)
     elif kind == "inv":  # w = y * T ; x' = x + w ; y' = x - w
         mul(y0, y1, d0, d1)
-        sub(y0, y1, x0, x1, d0, d1, y0, y1, y0, y1)
-        add(x0, x1, d0, d1, x0, x1)
+        sub(y0, y1, x0, x1, d0, d1, y0, y1, y0, y1)   # x may be any representative, w = d is canonical
+        lazy_add(x0, x1, d0, d1)
     elif kind == "mul":  # x' = x * T
         mul(x0, x1, x0, x1)
     return ins
@@ -246,7 +256,10 @@ def schedule(lists):
             dist = 0
             raw = ii.writes & ij.reads
             if raw:
-                dist = max(dist, SGPR_DIST if any(is_sgpr(r) for r in raw) else 1)
+                # the two-wait-state hazard is VALU writes SGPR/VCC -> VALU reads it; the scalar unit interlocks
+                # (hipcc itself emits v_cmp + s_and_saveexec and s_mov + v_add back to back)
+                hazard = any(is_sgpr(r) for r in raw) and not ii.salu and not ij.salu
+                dist = max(dist, SGPR_DIST if hazard else 1)
             if (ii.reads & ij.writes) or (ii.writes & ij.writes):
                 dist = max(dist, 1)
             if dist:
@@ -309,7 +322,7 @@ def emit(kind, nb, tw_constraint, vbase=104, suffix=""):
             outs += [f'[y0_{b}] "+v"(y0_{b})', f'[y1_{b}] "+v"(y1_{b})']
             outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("d0_", "d1_")]
         ins_ += [f'[t0_{b}] "{tw_constraint}"(t0_{b})', f'[t1_{b}] "{tw_constraint}"(t1_{b})']
-    if kind != "mul":
+    if kind == "fwd":
         ins_ += ['[pp] "s"(0xFFFFFFFF00000001ull)']  # p, for the 64-bit compare of the modular add
     clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 12 * nb)] + [f'"s{r}"' for r in range(84, 84 + 8 * nb)]
     src.append("        : " + ", ".join(outs))
