@@ -1,6 +1,6 @@
 // pass.h -- one HBM pass of the butterfly network: a group of consecutive stages
-// executed on a workgroup-resident tile, radix-16 register rounds exchanged
-// through LDS.
+// executed on a workgroup-resident tile, radix-E register rounds (E = 16 or 8 words per
+// thread) exchanged in place through LDS.
 //
 // What it replaces (file:line under the reference tree):
 //   src/aie_core.cc:189-361  ntt_stage0_to_Nminus5  tile-local stages on a
@@ -22,13 +22,13 @@
 // polynomial.  So a workgroup fixes (hi, lo-tile), keeps its twiddles in
 // registers and streams polynomials of the batch through them.
 //
-// A thread owns E = 16 words whose `mid` differ in a 4-bit window [b0, b0+4);
-// a round runs up to 4 stages on them in registers, then the tile is exchanged
-// in place through padded LDS and the next round uses the next window.
+// A thread owns E words whose `mid` differ in a log2(E)-bit window [b0, b0+log2 E);
+// a round runs up to log2(E) stages on them in registers, then the tile is exchanged
+// in place through LDS and the next round uses the next window.
 //
 // The body is written as phases over a thread context so that the very same
-// code runs on the GPU (one context per lane, __syncthreads between phases) and
-// in the host index model (tests/emu: all 256 contexts stepped phase by phase).
+// code runs on the GPU (one context per lane, barriers between phases where a unit spans
+// several waves) and in the host index model (tests/emu: all contexts stepped phase by phase).
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
