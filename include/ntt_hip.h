@@ -46,7 +46,7 @@ enum {
     NTT_E_PRIME = -2,      /* p even, p >= 2^32 for 4-byte words, or not Goldilocks for 8-byte words */
     NTT_E_LOGN = -3,       /* logn outside [1, NTT_MAX_LOGN] */
     NTT_E_NOTABLE = -4,    /* transform requested before ntt_plan_set_twiddles */
-    NTT_E_NOTINVERTIBLE = -5, /* inverse requested but a needed twiddle is 0 mod p */
+    NTT_E_NOTINVERTIBLE = -5, /* inverse requested but a twiddle is not a unit mod p (0, or shares a factor with a composite p) */
     NTT_E_LAYOUT = -6,     /* NTT_LAYOUT_AIE_BLOCK16 needs N >= 16 */
     NTT_E_RANGE = -7,      /* a twiddle handed to set_twiddles is >= p */
     NTT_E_NODEVICE = -8    /* no HIP device / device index out of range */

@@ -192,7 +192,7 @@ const char *ntt_error_string(int code) {
         case NTT_E_PRIME: return "unsupported modulus for this word size";
         case NTT_E_LOGN: return "logn out of range";
         case NTT_E_NOTABLE: return "twiddle table not set";
-        case NTT_E_NOTINVERTIBLE: return "twiddle table has an entry that is 0 mod p";
+        case NTT_E_NOTINVERTIBLE: return "twiddle table has an entry that is not a unit mod p";
         case NTT_E_LAYOUT: return "AIE_BLOCK16 layout needs N >= 16";
         case NTT_E_RANGE: return "twiddle out of range [0, p)";
         case NTT_E_NODEVICE: return "no such HIP device";
