@@ -75,6 +75,8 @@ def main():
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the twiddle broadcast path")
     args = ap.parse_args()
 
+    # the host driver only supports dmabuf IPC: RCCL across processes needs this (already exported on the GPU boxes)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist
