@@ -147,6 +147,16 @@ def main():
     }
 
     if rank == 0:
+        # per-step distribution (median and min): one hipEvent pair per step on the launch stream
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.steps, 5))]
+        for e0, e1 in evs:
+            e0.record(stream)
+            plan.forward(x, y, stream=stream)
+            e1.record(stream)
+        torch.cuda.synchronize()
+        step_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        out["step_ms_median"] = step_ms[len(step_ms) // 2]
+        out["step_ms_min"] = step_ms[0]
         # roofline: per-pass kernel durations from hipEvents on the launch stream
         reps = max(5, min(args.steps, 20))
         per_pass = np.zeros(plan.hbm_passes)
