@@ -177,6 +177,14 @@ def main():
             if all(nm in k for nm in names):  # counters collected for this build's kernels
                 traffic = sum(k[nm]["hbm_bytes_per_launch"] for nm in names)
                 traffic_src = "profiles/r01_pmc_traffic.json"
+        # the vector ALU's share of the kernel cycles from the SQ counters of the same command (profiles/r01_sq_counters.json):
+        # for this integer workload the binding unit is the VALU, not HBM and not MFMA
+        valu_busy = None
+        sq = os.path.join(ROOT, "profiles", "r01_sq_counters.json")
+        if os.path.exists(sq) and logn == 16 and batch == 4096:
+            k = json.load(open(sq))["kernels"]
+            if all(nm in k for nm in names):
+                valu_busy = [k[nm]["valu_busy_frac_of_kernel"] for nm in names]
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -185,6 +193,7 @@ def main():
                           "same launches" % plan.hbm_passes,
             "algorithmic_bytes_per_transform": 2 * n * 8, "passes": plan.hbm_passes,
             "pass_stages": [stages for _, _, stages in plan.passes],
+            "valu_busy_frac_per_pass": valu_busy, "valu_busy_source": "profiles/r01_sq_counters.json" if valu_busy else None,
             "pass_ms": [float(v) for v in per_pass], "dominant_pass": dom,
             # each pass kernel reads and writes every coefficient once: its own stream rate
             "pass_stream_GBs": [alg_bytes / (float(v) * 1e-3) / 1e9 for v in per_pass],
