@@ -87,7 +87,8 @@ struct ntt_plan {
     bool has_table, has_inv;
     uint64_t scale_tf;     // N^-1 in table form
     uint64_t ninv_plain;   // N^-1 plain
-    uint32_t target_wgs;
+    uint32_t target_wgs;      // workgroups per launch the batch loop of a CONTIG pass is sized for
+    uint32_t target_wgs_col;  // ... of a column pass (shorter loops win there)
     int dbg;
     int fused;         // NTT_FUSED=1: N = 2^16 Goldilocks forward through the XCD-local fused launch
     void *d_fused_ctl;  // counters of the fused launch (plan-owned)
@@ -110,7 +111,7 @@ ntt::ErasedArgs base_args(const ntt_plan *pl, const PassDesc &pd, const void *in
     a.n = pl->logn;
     a.s0 = pd.s0;
     a.batch = (uint32_t) batch;
-    a.target_wgs = pl->target_wgs;
+    a.target_wgs = pd.contig ? pl->target_wgs : pl->target_wgs_col;
     a.dbg = pl->dbg;
     return a;
 }
@@ -239,6 +240,12 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     if (const char *e = getenv("NTT_TARGET_WGS")) {
         long v = atol(e);
         if (v > 0 && v < (1 << 24)) pl->target_wgs = (uint32_t) v;
+    }
+    // column passes: 16384 (their tile streams 8 polynomials per workgroup at N = 2^16, batch 4096, instead of 16): -4 %
+    pl->target_wgs_col = 2 * pl->target_wgs;
+    if (const char *e = getenv("NTT_TARGET_WGS_COL")) {
+        long v = atol(e);
+        if (v > 0 && v < (1 << 24)) pl->target_wgs_col = (uint32_t) v;
     }
     pl->dbg = 0;
     if (const char *e = getenv("NTT_DEBUG_FLAGS")) pl->dbg = atoi(e);
