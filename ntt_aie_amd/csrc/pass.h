@@ -577,7 +577,10 @@ NTT_HD void phase_lds_write(Ctx<Cfg> &c, typename Cfg::W *lds) {
 // On the device the Goldilocks butterflies run as hand-scheduled instruction streams,
 // two independent butterflies per statement (gl_asm.h); everything else, and the host
 // index model, uses the portable Field arithmetic -- same words either way.
-template <class Cfg, int r>
+// M32_MODE: which 4-byte-word instruction stream runs (0 lazy p < 2^30, 1 p < 2^31, 2 any); -1 = decide here from
+// the kernel argument.  The GPU kernels decide ONCE, around the whole pass (pass_kernel.inc): a branch per asm
+// statement made hipcc reconcile the register assignment of the three arms with ~250 v_mov per polynomial.
+template <class Cfg, int r, int M32_MODE = -1>
 NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
     using W = typename Cfg::W;
     constexpr int b0 = Cfg::win(r);
@@ -593,7 +596,7 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
             // four independent butterflies per statement.  p < 2^30: values stay in [0, 2p) between butterflies,
             // rounds and passes (10 / 11 instructions, phase_canon() at the end of the transform); p < 2^31:
             // canonical values, carry-free v_min_u32 corrections (12); otherwise carry / borrow selects.
-            const int mode = f.p < 0x40000000u ? 0 : (f.p < 0x80000000u ? 1 : 2);  // kernel argument: wave-uniform branch
+            const int mode = M32_MODE >= 0 ? M32_MODE : (f.p < 0x40000000u ? 0 : (f.p < 0x80000000u ? 1 : 2));  // uniform
             static_for<0, Cfg::E / 8>([&](auto pp) {
                 constexpr int k0 = 4 * decltype(pp)::value;
                 constexpr int e0 = (((k0 + 0) >> t) << (t + 1)) | ((k0 + 0) & ((1 << t) - 1));
@@ -723,7 +726,7 @@ NTT_HD void wave_prio(int level) {
 // ---- the schedule (src/aie2.py:166-315, collapsed) ----------------------------
 // Exec supplies: each(fn) -- run fn(ctx) for this lane (GPU) or for all 256
 // contexts (host model); sync() -- workgroup barrier; lds() -- the tile.
-template <class Cfg, class Exec>
+template <class Cfg, class Exec, int M32_MODE = -1>
 NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     using C = Ctx<Cfg>;
     constexpr int R = Cfg::R;
@@ -776,7 +779,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         static_for<0, R>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             constexpr int r = Cfg::INV ? R - 1 - k : k;
-            ex.each([&](C &c) { phase_compute<Cfg, r>(c, a); });
+            ex.each([&](C &c) { phase_compute<Cfg, r, M32_MODE>(c, a); });
             if constexpr (k < R - 1) {
                 constexpr int rn = Cfg::INV ? r - 1 : r + 1;
                 if constexpr (LATE_SYNC && k == 0) {
