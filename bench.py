@@ -10,10 +10,16 @@ buffer, both already in HBM).  Weak scaling: every rank owns `batch` polynomials
 talks to the others in the timed region; the only collective is the one-off twiddle-table
 broadcast from rank 0 (RCCL).  Rank 0 prints ONE JSON line.
 
-Extra legs on rank 0 at N=1: per-pass kernel durations from hipEvents (roofline) and the CPU
-baseline (the oracle restatement of src/test.cpp:34-60, timed on a bounded sample).
+Every number of the `roofline` object is measured in THIS run on rank 0 -- per-pass kernel durations
+(hipEvents on the launch stream), a device copy of the same bytes (the achievable stream rate beside
+the 8 TB/s spec peak), the VALU floor (the same kernels of the experiment build with their loads
+served from L2 and their stores skipped) -- except the hardware-counter figures (`traffic`, VALU
+instruction counts), which need rocprofv3: those are read from profiles/ and quoted ONLY when the
+kernel-source hash stamped into them equals the hash of the tree this run executes (null otherwise).
+The CPU baseline is the oracle restatement of src/test.cpp:34-60 timed on a bounded sample.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -23,15 +29,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GOLDILOCKS = 0xFFFFFFFF00000001
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable by a float4 copy
+SEED = 0x9E3779B97F4A7C15  # a[b][i] = splitmix64(SEED + b*N + i) mod p
+PROFILE_ROUND = "r02"
 
 
-def synth_batch(torch, batch, n, device, seed):
-    """Canonical residues covering (almost) the full range [0, p): hi word <= 2^32-2."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    hi = torch.randint(0, 0xFFFFFFFF, (batch, n), dtype=torch.int64, device=device, generator=g)
-    lo = torch.randint(0, 1 << 32, (batch, n), dtype=torch.int64, device=device, generator=g)
-    return (hi << 32) | lo
+def _s64(v: int) -> int:
+    """64-bit pattern as the signed value torch.int64 holds."""
+    v &= (1 << 64) - 1
+    return v - (1 << 64) if v >> 63 else v
+
+
+def splitmix64_words(torch, first_index: int, count: int, device):
+    """splitmix64 of the words first_index .. first_index+count-1: z = index + 0x9E3779B97F4A7C15, then the generator's
+    two xor-shift-multiply rounds and final xor-shift.  Returned as bit patterns in an int64 tensor (int64
+    arithmetic wraps; logical right shifts are arithmetic shifts masked)."""
+    z = torch.arange(count, dtype=torch.int64, device=device) + _s64(first_index + 0x9E3779B97F4A7C15)
+
+    def lsr(v, k):
+        return (v >> k) & ((1 << (64 - k)) - 1)
+
+    z = (z ^ lsr(z, 30)) * _s64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * _s64(0x94D049BB133111EB)
+    return z ^ lsr(z, 31)
+
+
+def synth_batch(torch, batch, n, device, seed=SEED, first_row=0):
+    """[batch][n] canonical Goldilocks residues: a[b][i] = splitmix64(seed + (first_row + b)*n + i) mod p.
+    A 64-bit word u is >= p only in [p, 2^64) = the signed range [-(2^32-1), -1], where u - p = u + 2^32 - 1."""
+    out = torch.empty((batch, n), dtype=torch.int64, device=device)
+    rows = max(1, (1 << 24) // n)  # 128 MiB of temporaries at a time
+    for r0 in range(0, batch, rows):
+        r1 = min(batch, r0 + rows)
+        z = splitmix64_words(torch, seed + (first_row + r0) * n, (r1 - r0) * n, device)
+        z = torch.where((z < 0) & (z >= -(2**32 - 1)), z + (2**32 - 1), z)
+        out[r0:r1] = z.view(r1 - r0, n)
+    return out
 
 
 def cpu_baseline(logn, p, table, cpu_seconds=20.0):
@@ -61,6 +94,74 @@ def cpu_baseline(logn, p, table, cpu_seconds=20.0):
             "sample": "%d polynomials of N=2^%d on %d threads (%.2f s); 1-thread rate %.1f NTT/s"
                       % (sample, logn, cores, tn, rate_1),
             "value_1thread": rate_1, "butterflies_per_s": best * (n // 2) * logn}
+
+
+def device_copy_rate(torch, x, y, stream, reps=10):
+    """The achievable stream rate of this device, in this process, on these buffers: read every byte of x once and
+    write it once to y (the same algorithmic bytes as one transform).  Two forms, best kept: the runtime's
+    device-to-device copy and a plain elementwise kernel."""
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    nbytes = 2.0 * x.numel() * x.element_size()
+    ms_copy = timed(lambda: y.copy_(x))
+    ms_elem = timed(lambda: torch.bitwise_xor(x, 1, out=y))
+    best = min(ms_copy, ms_elem)
+    return {"GBs": nbytes / (best * 1e-3) / 1e9, "ms": best, "ms_memcpy_d2d": ms_copy, "ms_elementwise_kernel": ms_elem,
+            "bytes": nbytes}
+
+
+def valu_floor(torch, logn, p, batch, x, y, stream, reps=5):
+    """The same pass kernels with every iteration's loads redirected to polynomial group 0 (L2-resident) and the
+    stores skipped: what the butterflies + LDS exchanges cost with no HBM traffic.  Runs the experiment build
+    (libntt_hip_exp.so = the same sources + -DNTT_EXPERIMENT; the product library has no such switch); outputs of
+    these launches are meaningless and go to the scratch buffer y."""
+    path = os.path.join(ROOT, "ntt_aie_amd", "libntt_hip_exp.so")
+    if not os.path.exists(path):
+        return None
+    from ntt_aie_amd import _lib
+
+    L = _lib.open_library(path)
+    os.environ["NTT_DEBUG_FLAGS"] = "3"
+    h = C.c_void_p()
+    try:
+        if L.ntt_plan_create(C.byref(h), logn, p, 8, x.device.index) != 0:
+            return None
+    finally:
+        del os.environ["NTT_DEBUG_FLAGS"]
+    try:
+        if L.ntt_plan_generate_twiddles(h, 0, 7) != 0:
+            return None
+        ms, k = (C.c_float * 8)(), C.c_int(0)
+        best = None
+        for _ in range(reps + 1):
+            if L.ntt_forward_profile(h, x.data_ptr(), y.data_ptr(), batch, 0, stream.cuda_stream, ms, 8, C.byref(k)) != 0:
+                return None
+            cur = [float(ms[i]) for i in range(k.value)]
+            best = cur if best is None or sum(cur) < sum(best) else best
+        return best
+    finally:
+        L.ntt_plan_destroy(h)
+
+
+def tagged_profile(name, src_hash):
+    """profiles/<round>_<name>.json if it was collected on exactly these kernel sources, else (None, reason)."""
+    path = os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_ROUND, name))
+    if not os.path.exists(path):
+        return None, "profiles/%s_%s.json absent" % (PROFILE_ROUND, name)
+    d = json.load(open(path))
+    if d.get("src_hash") != src_hash:
+        return None, "profiles/%s_%s.json was collected on kernel sources %s, this tree is %s: not quoted" % (
+            PROFILE_ROUND, name, d.get("src_hash"), src_hash)
+    return d, "profiles/%s_%s.json (src_hash %s)" % (PROFILE_ROUND, name, src_hash)
 
 
 def main():
@@ -104,12 +205,14 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    from ntt_aie_amd import _lib
     from ntt_aie_amd.dist import ShardedNTT
 
     logn, n, batch, p = args.logn, 1 << args.logn, args.batch, GOLDILOCKS
     eng = ShardedNTT(logn, p, g=7, word_bytes=8, device=local_rank)  # rank 0 makes the table, RCCL broadcast
     plan = eng.plan
-    x = synth_batch(torch, batch, n, dev, seed=1234 + rank)
+    # rank r holds rows [r*batch, (r+1)*batch) of the job's [world*batch][N] input
+    x = synth_batch(torch, batch, n, dev, first_row=rank * batch)
     y = torch.empty_like(x)
     stream = torch.cuda.current_stream()
 
@@ -135,18 +238,25 @@ def main():
 
     total_ntt = batch * world * args.steps
     value = total_ntt / elapsed
+    note5 = ("; BASELINE config 5 (batch 65536 over 8 GPUs) is 8192 per GPU: run with --batch 8192" if world > 1 and batch != 8192
+             else "")
     out = {
         "metric": "forward-NTT/s, N=2^%d 64-bit Goldilocks prime, batch=%d per GPU" % (logn, batch),
         "value": value, "unit": "NTT/s", "butterflies_per_s": value * (n // 2) * logn,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "N=2^%d forward NTT, p=2^64-2^32+1, make_roots table g=7, batch=%d per GPU, "
-                               "out-of-place, inputs resident in HBM" % (logn, batch),
-                   "hbm_passes": plan.hbm_passes, "sharding": "batch rows, no data-path collective"},
+        "config": {"workload": "N=2^%d forward NTT, p=2^64-2^32+1, make_roots table g=7, batch=%d per GPU (%d in the job, weak "
+                               "scaling of the headline configuration%s), out-of-place, inputs resident in HBM, "
+                               "a[b][i] = splitmix64(0x9E3779B97F4A7C15 + b*N + i) mod p" % (logn, batch, batch * world, note5),
+                   "batch_per_gpu": batch, "hbm_passes": plan.hbm_passes,
+                   "sharding": "contiguous batch rows per rank, no data-path collective",
+                   "table_broadcast": (dist.get_backend() if use_dist else "none (single process)"),
+                   "kernel_src_hash": _lib.kernel_source_hash()},
     }
 
     if rank == 0:
+        src_hash = _lib.kernel_source_hash()
         # per-step distribution (median and min): one hipEvent pair per step on the launch stream
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(args.steps, 5))]
         for e0, e1 in evs:
@@ -167,37 +277,45 @@ def main():
         t_kernels = float(per_pass.sum()) * 1e-3
         achieved = alg_bytes / t_kernels / 1e9
         dom = int(per_pass.argmax())
-        # HBM bytes per launch from the PMC counters (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
-        # same command, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_pmc_traffic.json
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         names = ["pass_%s_%d" % (kind, stages) for kind, _, stages in plan.passes]
-        if os.path.exists(pmc) and logn == 16 and batch == 4096:
-            k = json.load(open(pmc))["kernels"]
-            if all(nm in k for nm in names):  # counters collected for this build's kernels
-                traffic = sum(k[nm]["hbm_bytes_per_launch"] for nm in names)
-                traffic_src = "profiles/r01_pmc_traffic.json"
-        # the vector ALU's share of the kernel cycles from the SQ counters of the same command (profiles/r01_sq_counters.json):
-        # for this integer workload the binding unit is the VALU, not HBM and not MFMA
-        valu_busy = None
-        sq = os.path.join(ROOT, "profiles", "r01_sq_counters.json")
-        if os.path.exists(sq) and logn == 16 and batch == 4096:
-            k = json.load(open(sq))["kernels"]
-            if all(nm in k for nm in names):
-                valu_busy = [k[nm]["valu_busy_frac_of_kernel"] for nm in names]
+        headline = logn == 16 and batch == 4096
+        # measured here: what a plain copy of the same bytes achieves, and the VALU floor of the same kernels
+        copy = device_copy_rate(torch, x, y, stream)
+        floor = valu_floor(torch, logn, p, batch, x, y, stream)
+        # counters (rocprofv3 --pmc, separate runs of this command): quoted only when collected on these sources
+        traffic, traffic_src = None, "counters are collected for the headline configuration only"
+        valu_cnt, valu_src = None, traffic_src
+        if headline:
+            d, traffic_src = tagged_profile("pmc_traffic", src_hash)
+            if d and all(nm in d["kernels"] for nm in names):
+                traffic = sum(d["kernels"][nm]["hbm_bytes_per_launch"] for nm in names)
+            d, valu_src = tagged_profile("sq_counters", src_hash)
+            if d and all(nm in d["kernels"] for nm in names):
+                valu_cnt = {"instr_per_butterfly": [d["kernels"][nm]["valu_instr_per_butterfly"] for nm in names],
+                            "instr_x_4cyc_over_kernel_cycles": [d["kernels"][nm]["valu_instr_x4cyc_over_kernel_cycles"] for nm in names],
+                            "what": "SQ_INSTS_VALU per butterfly, and SQ_INSTS_VALU x an ASSUMED 4 cycles / (1024 SIMDs x kernel "
+                                    "cycles): an instruction-count estimate of VALU occupancy, not a busy-cycle measurement"}
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "definition": "algorithmic bytes of one forward transform (2*N*8 B) x batch / summed duration of its "
-                          "%d pass kernels (hipEvents on the launch stream); traffic = PMC HBM bytes of the "
-                          "same launches" % plan.hbm_passes,
-            "algorithmic_bytes_per_transform": 2 * n * 8, "passes": plan.hbm_passes,
-            "pass_stages": [stages for _, _, stages in plan.passes],
-            "valu_busy_frac_per_pass": valu_busy, "valu_busy_source": "profiles/r01_sq_counters.json" if valu_busy else None,
+                          "%d pass kernels (hipEvents on the launch stream); a %d-pass transform physically moves %dx its "
+                          "algorithmic bytes, so its ceiling is frac %.2f; traffic = PMC HBM bytes of the same launches"
+                          % (plan.hbm_passes, plan.hbm_passes, plan.hbm_passes, 1.0 / plan.hbm_passes),
+            "algorithmic_bytes_per_transform": 2 * n * 8, "algorithmic_bytes_per_launch": alg_bytes,
+            "passes": plan.hbm_passes, "pass_stages": [stages for _, _, stages in plan.passes],
             "pass_ms": [float(v) for v in per_pass], "dominant_pass": dom,
             # each pass kernel reads and writes every coefficient once: its own stream rate
             "pass_stream_GBs": [alg_bytes / (float(v) * 1e-3) / 1e9 for v in per_pass],
             "pass_stream_frac": [alg_bytes / (float(v) * 1e-3) / 1e9 / HBM_PEAK_GBS for v in per_pass],
+            # the same bytes through a plain copy, same process, same buffers: the achievable rate beside the spec peak
+            "device_copy": copy, "frac_of_device_copy": achieved / copy["GBs"],
+            "pass_stream_frac_of_device_copy": [alg_bytes / (float(v) * 1e-3) / 1e9 / copy["GBs"] for v in per_pass],
+            # the binding unit of this integer workload is the vector ALU: floor = the same kernels, loads from L2, no stores
+            "valu_floor_pass_ms": floor,
+            "valu_floor_frac_of_pass": ([f / float(v) for f, v in zip(floor, per_pass)] if floor else None),
+            "valu_floor_source": "measured in this run: libntt_hip_exp.so, NTT_DEBUG_FLAGS=3" if floor else "libntt_hip_exp.so absent",
+            "valu_counters": valu_cnt, "valu_counters_source": valu_src,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(logn, p, eng.table)

@@ -34,6 +34,49 @@ EXPORTS = (
 )
 
 
+def kernel_source_hash() -> str:
+    """16 hex digits over the device-code sources (csrc/*.h, *.inc, *.hip): the identity of the kernels a profile was
+    collected on.  bench.py and tools/*_summary.py stamp it into what they write, and bench.py refuses to quote
+    counter values whose stamp differs from the tree it runs in."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    for f in sorted(glob.glob(os.path.join(src, "*.h")) + glob.glob(os.path.join(src, "*.inc")) + glob.glob(os.path.join(src, "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def open_library(path: str) -> C.CDLL:
+    """dlopen one build of the C-ABI and declare its signatures (the product library, or tools' experiment build)."""
+    L = C.CDLL(path)
+    vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
+    L.ntt_version.restype = C.c_int
+    L.ntt_error_string.restype = C.c_char_p
+    L.ntt_error_string.argtypes = [C.c_int]
+    L.ntt_device_count.restype = C.c_int
+    L.ntt_plan_create.argtypes = [C.POINTER(vp), C.c_int, u64, C.c_int, C.c_int]
+    L.ntt_plan_destroy.argtypes = [vp]
+    L.ntt_plan_set_twiddles.argtypes = [vp, vp]
+    L.ntt_make_roots.argtypes = [vp, u64, vp]
+    L.ntt_make_table.argtypes = [vp, C.c_int, u64, vp]
+    L.ntt_plan_generate_twiddles.argtypes = [vp, C.c_int, u64]
+    L.ntt_plan_get_twiddles.argtypes = [vp, C.c_int, vp]
+    L.ntt_plan_info.restype = C.c_int64
+    L.ntt_plan_info.argtypes = [vp, C.c_int]
+    L.ntt_forward.argtypes = [vp, vp, vp, sz, C.c_int, vp]
+    L.ntt_forward_profile.argtypes = [vp, vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float), C.c_int,
+                                      C.POINTER(C.c_int)]
+    L.ntt_inverse.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, vp]
+    L.ntt_pointwise_mul.argtypes = [vp, vp, vp, vp, sz, u64, vp]
+    L.ntt_polymul_negacyclic.argtypes = [vp, vp, vp, vp, sz, vp]
+    L.ntt_count_noncanonical.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64)]
+    L.ntt_forward_stages.argtypes = [vp, vp, vp, sz, C.c_int, vp]
+    return L
+
+
 class NTTError(RuntimeError):
     def __init__(self, code: int, where: str):
         self.code = code
@@ -59,29 +102,7 @@ def lib() -> C.CDLL:
             import torch  # noqa: F401
         except ImportError:
             pass
-        L = C.CDLL(LIB_PATH)
-        vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
-        L.ntt_version.restype = C.c_int
-        L.ntt_error_string.restype = C.c_char_p
-        L.ntt_error_string.argtypes = [C.c_int]
-        L.ntt_device_count.restype = C.c_int
-        L.ntt_plan_create.argtypes = [C.POINTER(vp), C.c_int, u64, C.c_int, C.c_int]
-        L.ntt_plan_destroy.argtypes = [vp]
-        L.ntt_plan_set_twiddles.argtypes = [vp, vp]
-        L.ntt_make_roots.argtypes = [vp, u64, vp]
-        L.ntt_make_table.argtypes = [vp, C.c_int, u64, vp]
-        L.ntt_plan_generate_twiddles.argtypes = [vp, C.c_int, u64]
-        L.ntt_plan_get_twiddles.argtypes = [vp, C.c_int, vp]
-        L.ntt_plan_info.restype = C.c_int64
-        L.ntt_plan_info.argtypes = [vp, C.c_int]
-        L.ntt_forward.argtypes = [vp, vp, vp, sz, C.c_int, vp]
-        L.ntt_forward_profile.argtypes = [vp, vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float), C.c_int,
-                                          C.POINTER(C.c_int)]
-        L.ntt_inverse.argtypes = [vp, vp, vp, sz, C.c_int, C.c_int, vp]
-        L.ntt_pointwise_mul.argtypes = [vp, vp, vp, vp, sz, u64, vp]
-        L.ntt_polymul_negacyclic.argtypes = [vp, vp, vp, vp, sz, vp]
-        L.ntt_count_noncanonical.argtypes = [vp, vp, sz, C.POINTER(C.c_uint64)]
-        L.ntt_forward_stages.argtypes = [vp, vp, vp, sz, C.c_int, vp]
+        L = open_library(LIB_PATH)
         _lib = L
     return _lib
 

@@ -22,7 +22,7 @@ struct ErasedArgs {
     int dbg;  // timing experiments (NTT_DEBUG_FLAGS), 0 in production
     const void *in2;     // forward CONTIG pass: second operand of a fused pointwise product (or null)
     uint64_t pw_scale;   // scale * R^2 (see PassArgs::pw_scale)
-    const void *skip_if;  // device word: when non-zero the launch is a no-op (fallback behind the fused kernel)
+    const void *skip_if;  // experiment build only: device word, non-zero = the launch is a no-op (fallback behind the fused kernel)
 };
 
 // Each returns hipSuccess / a hipError_t; hipErrorInvalidValue for an
@@ -32,12 +32,15 @@ hipError_t launch_gl_inv(bool contig, int log_m, const ErasedArgs &a, hipStream_
 hipError_t launch_m32_fwd(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
 hipError_t launch_m32_inv(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
 
-// N = 2^16 Goldilocks forward as one persistent XCD-local launch (fused_gl16.hip): memset + fused +
+#if defined(NTT_EXPERIMENT)
+// Tools-side experiment, NOT part of libntt_hip.so (tools/fused_gl16.hip, libntt_hip_exp.so only):
+// N = 2^16 Goldilocks forward as one persistent XCD-local launch: memset + fused +
 // check; must be followed by the ordinary passes with skip_if = fused_gl16_ok_word(ctl).
 size_t fused_gl16_ctl_bytes(size_t max_batch);
 const void *fused_gl16_ok_word(const void *ctl);
 hipError_t launch_fused_gl16(const void *in, void *out, const void *tw, size_t batch, void *ctl_mem, hipStream_t s,
                              int dbg = 0);
+#endif
 
 // elementwise c = a*b*scale (scale in plain form; scale == 1 skips the second product)
 hipError_t launch_pointwise_gl(const void *a, const void *b, void *c, size_t count, uint64_t scale,

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -89,10 +90,12 @@ struct ntt_plan {
     uint64_t ninv_plain;   // N^-1 plain
     uint32_t target_wgs;      // workgroups per launch the batch loop of a CONTIG pass is sized for
     uint32_t target_wgs_col;  // ... of a column pass (shorter loops win there)
-    int dbg;
-    int fused;         // NTT_FUSED=1: N = 2^16 Goldilocks forward through the XCD-local fused launch
-    void *d_fused_ctl;  // counters of the fused launch (plan-owned)
+    int dbg;            // experiment build only (NTT_DEBUG_FLAGS); always 0 in the product
+    int fused;          // experiment build only (NTT_FUSED=1): N = 2^16 Goldilocks forward through the XCD-local fused launch
+    void *d_fused_ctl;  // counters of the fused launch (plan-owned; null in the product)
     size_t fused_max_batch;
+    unsigned long long *d_counter;  // one device word for ntt_count_noncanonical (no allocation per call)
+    std::mutex counter_mu;          // ... which is the only entry point that writes plan-owned state after creation
     std::vector<PassDesc> passes;
 };
 
@@ -133,6 +136,7 @@ int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
     RoctxRange whole(in2 ? "ntt_forward(product)" : "ntt_forward");
     const void *src = d_in;
     const void *skip_if = nullptr;
+#if defined(NTT_EXPERIMENT)
     if (pl->d_fused_ctl && !in2 && d_in != d_out && layout == NTT_LAYOUT_NATURAL && batch >= 64 && batch % 8 == 0 &&
         batch <= pl->fused_max_batch) {
         // one persistent XCD-local launch; the ordinary passes below then only run (device-side
@@ -142,6 +146,7 @@ int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
         skip_if = ntt::fused_gl16_ok_word(pl->d_fused_ctl);
         if (pl->dbg & (16 | 32 | 64)) return NTT_OK;  // timing experiments: fused launch alone
     }
+#endif
     for (const PassDesc &pd : pl->passes) {
         RoctxRange pass("fwd pass", pd.contig, pd.s0, pd.log_m);
         ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
@@ -237,24 +242,28 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     pl->ninv_plain = powmod((p + 1) / 2, (uint64_t) logn, p);  // (2^-1)^logn; p + 1 < 2^64
     pl->scale_tf = to_table_form(pl->ninv_plain, p, word_bytes);
     pl->target_wgs = 8192;  // workgroups per launch the batch loop is sized for (sweep: profiles/)
-    if (const char *e = getenv("NTT_TARGET_WGS")) {
-        long v = atol(e);
-        if (v > 0 && v < (1 << 24)) pl->target_wgs = (uint32_t) v;
-    }
     // column passes: 16384 (their tile streams 8 polynomials per workgroup at N = 2^16, batch 4096, instead of 16): -4 %
     pl->target_wgs_col = 2 * pl->target_wgs;
+    pl->dbg = 0;
+    pl->fused = 0;
+    pl->d_fused_ctl = nullptr;
+    pl->fused_max_batch = 0;
+    pl->d_counter = nullptr;
+    pl->passes = plan_passes(logn, word_bytes);
+#if defined(NTT_EXPERIMENT)
+    // Experiment knobs exist only in libntt_hip_exp.so (make exp; tools/): the product library reads NO environment
+    // variable, so a stray NTT_DEBUG_FLAGS in a user's shell cannot redirect loads and stores.
+    if (const char *e = getenv("NTT_TARGET_WGS")) {
+        long v = atol(e);
+        if (v > 0 && v < (1 << 24)) pl->target_wgs = (uint32_t) v, pl->target_wgs_col = 2 * pl->target_wgs;
+    }
     if (const char *e = getenv("NTT_TARGET_WGS_COL")) {
         long v = atol(e);
         if (v > 0 && v < (1 << 24)) pl->target_wgs_col = (uint32_t) v;
     }
-    pl->dbg = 0;
     if (const char *e = getenv("NTT_DEBUG_FLAGS")) pl->dbg = atoi(e);
-    pl->fused = 0;
-    pl->d_fused_ctl = nullptr;
-    pl->fused_max_batch = 0;
     if (const char *e = getenv("NTT_FUSED")) pl->fused = atoi(e);
-    pl->passes = plan_passes(logn, word_bytes);
-    if (const char *e = getenv("NTT_PLAN_SPLIT")) {  // experiment knob: "8,6,6" = CONTIG 8 stages + two 6-stage column passes
+    if (const char *e = getenv("NTT_PLAN_SPLIT")) {  // "8,6,6" = CONTIG 8 stages + two 6-stage column passes
         std::vector<PassDesc> v;
         int s0 = 0;
         bool ok = true;
@@ -271,6 +280,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
         if (v.size() > 1 && v[0].log_m < ntt::col_log_c(word_bytes)) ok = false;  // column tiles are 2^log_c words wide
         if (ok && s0 == logn && !v.empty()) pl->passes = v;  // anything else: keep the default split
     }
+#endif
     DeviceGuard g(device);
     if (g.err != hipSuccess) {
         delete pl;
@@ -278,13 +288,17 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     }
     hipError_t e = hipMalloc(&pl->d_tw_fwd, table_bytes(pl));
     if (e == hipSuccess) e = hipMalloc(&pl->d_tw_inv, table_bytes(pl));
+    if (e == hipSuccess) e = hipMalloc(&pl->d_counter, sizeof(*pl->d_counter));
+#if defined(NTT_EXPERIMENT)
     if (e == hipSuccess && pl->fused && logn == 16 && word_bytes == 8) {
         pl->fused_max_batch = (size_t) 1 << 20;
         e = hipMalloc(&pl->d_fused_ctl, ntt::fused_gl16_ctl_bytes(pl->fused_max_batch));
     }
+#endif
     if (e != hipSuccess) {
         if (pl->d_tw_fwd) (void) hipFree(pl->d_tw_fwd);
         if (pl->d_tw_inv) (void) hipFree(pl->d_tw_inv);
+        if (pl->d_counter) (void) hipFree(pl->d_counter);
         delete pl;
         return (int) e;
     }
@@ -298,6 +312,7 @@ int ntt_plan_destroy(ntt_plan_t pl) {
     if (pl->d_tw_fwd) (void) hipFree(pl->d_tw_fwd);
     if (pl->d_tw_inv) (void) hipFree(pl->d_tw_inv);
     if (pl->d_fused_ctl) (void) hipFree(pl->d_fused_ctl);
+    if (pl->d_counter) (void) hipFree(pl->d_counter);
     delete pl;
     return NTT_OK;
 }
@@ -418,6 +433,7 @@ int64_t ntt_plan_info(ntt_plan_t pl, int what) {
     }
     if (what >= 32 && what < 32 + (int) pl->passes.size()) return pl->passes[what - 32].log_m;
     if (what >= 64 && what < 64 + (int) pl->passes.size()) return pl->passes[what - 64].s0;
+#if defined(NTT_EXPERIMENT)
     if (what >= 16 && what < 16 + 12 && pl->d_fused_ctl) {  // diagnostics: words of the last fused launch (blocking)
         uint32_t w[12];
         DeviceGuard g(pl->device);
@@ -425,6 +441,7 @@ int64_t ntt_plan_info(ntt_plan_t pl, int what) {
             return NTT_E_ARG;
         return w[what - 16];  // 0-7 slots per XCC, 8 status, 9 b_done, 10 ok
     }
+#endif
     return NTT_E_ARG;
 }
 
@@ -452,9 +469,17 @@ int ntt_forward_profile(ntt_plan_t pl, const void *d_in, void *d_out, size_t bat
     if (g.err != hipSuccess) return (int) g.err;
     hipStream_t s = (hipStream_t) stream;
     const size_t np = pl->passes.size();
-    std::vector<hipEvent_t> ev(np + 1);
-    for (auto &e : ev)
-        if (hipEventCreate(&e) != hipSuccess) return (int) hipGetLastError();
+    std::vector<hipEvent_t> ev;
+    ev.reserve(np + 1);
+    for (size_t i = 0; i <= np; i++) {
+        hipEvent_t x;
+        const hipError_t ce = hipEventCreate(&x);
+        if (ce != hipSuccess) {  // destroy the ones already made
+            for (auto &y : ev) (void) hipEventDestroy(y);
+            return (int) ce;
+        }
+        ev.push_back(x);
+    }
     const void *src = d_in;
     hipError_t e = hipEventRecord(ev[0], s);
     for (size_t i = 0; i < np && e == hipSuccess; i++) {
@@ -532,14 +557,12 @@ int ntt_count_noncanonical(ntt_plan_t pl, const void *d_buf, size_t batch, uint6
     if (!d_buf) return NTT_E_ARG;
     DeviceGuard g(pl->device);
     if (g.err != hipSuccess) return (int) g.err;
-    unsigned long long *d_cnt = nullptr;
-    hipError_t e = hipMalloc(&d_cnt, sizeof(*d_cnt));
-    if (e != hipSuccess) return (int) e;
-    e = hipMemset(d_cnt, 0, sizeof(*d_cnt));
+    std::lock_guard<std::mutex> lock(pl->counter_mu);  // the plan's one counter word
+    unsigned long long *d_cnt = pl->d_counter;
+    hipError_t e = hipMemset(d_cnt, 0, sizeof(*d_cnt));
     if (e == hipSuccess) e = ntt::launch_count_noncanonical(d_buf, batch << pl->logn, pl->word_bytes, pl->p, d_cnt, nullptr);
     unsigned long long h = 0;
     if (e == hipSuccess) e = hipMemcpy(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost);
-    (void) hipFree(d_cnt);
     *host_count = h;
     return (int) e;
 }

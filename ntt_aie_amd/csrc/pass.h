@@ -201,7 +201,8 @@ struct PassArgs {
     W pw_scale;              // scale * R^2 in table form's domain: mul(mul(x, y), pw_scale) == x * y * scale
     int pg_stride;           // polynomial-group step per iteration (1 for the plain launches)
     const uint32_t *skip_if; // non-null: every workgroup returns at once when *skip_if != 0 (guarded fallback)
-    int dbg;       // timing experiments only: 1 = every iteration re-reads polynomial group 0,
+    int dbg;       // read only in the -DNTT_EXPERIMENT build (tools/, libntt_hip_exp.so), ignored by the product:
+                   // timing experiments: 1 = every iteration re-reads polynomial group 0,
                    // 2 = skip the direct stores, 4 = every iteration stores to polynomial group 0
     W scale;
 };
@@ -251,8 +252,13 @@ NTT_HD size_t uniform_word(const Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it, in
     const int log_ltb = Cfg::CONTIG ? 0 : a.s0 - Cfg::LOG_C - a.log_ul;
     const uint32_t ltb = Cfg::CONTIG ? 0u : (c.bx & ((1u << log_ltb) - 1u));
     const uint32_t hb = Cfg::CONTIG ? c.bx : (c.bx >> log_ltb);
+#if defined(NTT_EXPERIMENT)
     size_t pg = (a.dbg & dbg_bit) ? 0 : (size_t) c.pg_base + (size_t) it * (uint32_t) a.pg_stride;
     if (a.dbg & 8) pg &= (size_t) ((a.dbg >> 4) - 1);  // confine traffic to the first (dbg >> 4) polynomial groups
+#else
+    (void) dbg_bit;
+    const size_t pg = (size_t) c.pg_base + (size_t) it * (uint32_t) a.pg_stride;
+#endif
     return ((size_t) hb << (a.log_uh + a.s0 + Cfg::LOG_M)) + ((size_t) ltb << (a.log_ul + Cfg::LOG_C)) +
            (pg << (a.log_up + a.n));
 }
@@ -425,7 +431,10 @@ template <class Cfg, int r>
 NTT_HD void phase_store_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     using W = typename Cfg::W;
     W *ubase = a.out + uniform_word<Cfg>(c, a, it, 4);
-    if (!c.active || (a.dbg & 2)) return;
+    if (!c.active) return;
+#if defined(NTT_EXPERIMENT)
+    if (a.dbg & 2) return;
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t voff = c.lane_st * (uint32_t) sizeof(W);
     if constexpr (Cfg::DMA) {

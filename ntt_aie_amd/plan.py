@@ -130,11 +130,22 @@ class NTTPlan:
             stream = torch.cuda.current_stream()
         return stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream)
 
+    def _out_like(self, inp: torch.Tensor, stream) -> torch.Tensor:
+        """Output buffer for a launch on `stream`: allocated UNDER that stream, so that torch's caching allocator
+        ties the block's reuse to the stream the kernels run on (allocating on the current stream and launching on
+        another would let the allocator recycle the block while the transform is still writing it)."""
+        if stream is None:
+            return torch.empty_like(inp)
+        if not hasattr(stream, "cuda_stream"):  # a raw hipStream_t handle
+            stream = torch.cuda.ExternalStream(int(stream), device=inp.device)
+        with torch.cuda.stream(stream):
+            return torch.empty_like(inp)
+
     # ---- transforms ------------------------------------------------------------
     def forward(self, inp: torch.Tensor, out: torch.Tensor | None = None, layout: int = LAYOUT_NATURAL,
                 stream=None) -> torch.Tensor:
         """The reference network (src/test.cpp:34-60) on every polynomial of `inp`."""
-        out = torch.empty_like(inp) if out is None else out
+        out = self._out_like(inp, stream) if out is None else out
         b = self._batch(inp, out)
         check(_lib.lib().ntt_forward(self._h, inp.data_ptr(), out.data_ptr(), b, layout,
                                      self._stream(stream)), "ntt_forward")
@@ -143,7 +154,7 @@ class NTTPlan:
     def forward_profile(self, inp: torch.Tensor, out: torch.Tensor | None = None,
                         layout: int = LAYOUT_NATURAL, stream=None) -> list[float]:
         """forward() with a hipEvent pair around every HBM pass; returns ms per pass (blocking)."""
-        out = torch.empty_like(inp) if out is None else out
+        out = self._out_like(inp, stream) if out is None else out
         b = self._batch(inp, out)
         ms = (C.c_float * 8)()
         k = C.c_int(0)
@@ -153,7 +164,7 @@ class NTTPlan:
 
     def inverse(self, inp: torch.Tensor, out: torch.Tensor | None = None, layout: int = LAYOUT_NATURAL,
                 scale: bool = True, stream=None) -> torch.Tensor:
-        out = torch.empty_like(inp) if out is None else out
+        out = self._out_like(inp, stream) if out is None else out
         b = self._batch(inp, out)
         check(_lib.lib().ntt_inverse(self._h, inp.data_ptr(), out.data_ptr(), b, layout, int(scale),
                                      self._stream(stream)), "ntt_inverse")
@@ -161,7 +172,7 @@ class NTTPlan:
 
     def pointwise_mul(self, a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None,
                       scale: int = 1, stream=None) -> torch.Tensor:
-        out = torch.empty_like(a) if out is None else out
+        out = self._out_like(a, stream) if out is None else out
         n = self._batch(a, b, out)
         check(_lib.lib().ntt_pointwise_mul(self._h, a.data_ptr(), b.data_ptr(), out.data_ptr(), n, scale,
                                            self._stream(stream)), "ntt_pointwise_mul")
@@ -186,7 +197,7 @@ class NTTPlan:
     def forward_stages(self, inp: torch.Tensor, stage: int, out: torch.Tensor | None = None,
                        stream=None) -> torch.Tensor:
         """Stages 0..stage only (the reference's test_stage hook, src/test.cpp:55-58, 67)."""
-        out = torch.empty_like(inp) if out is None else out
+        out = self._out_like(inp, stream) if out is None else out
         b = self._batch(inp, out)
         check(_lib.lib().ntt_forward_stages(self._h, inp.data_ptr(), out.data_ptr(), b, stage,
                                             self._stream(stream)), "ntt_forward_stages")

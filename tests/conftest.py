@@ -25,14 +25,20 @@ def _gpu_present() -> bool:
 
 
 def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU: fail loudly rather than pass vacuously.
-    if config.getoption("-m") and "not gpu" in config.getoption("-m"):
+    """`-m gpu` on a box without a GPU must FAIL, not pass vacuously by skipping everything (the driver reads the
+    exit code).  A plain `pytest tests/` (no -m) on a CPU-only box skips the gpu-marked tests."""
+    expr = (config.getoption("-m") or "").strip()
+    if "not gpu" in expr:
         return
-    if not _gpu_present():
-        skip = pytest.mark.skip(reason="no GPU visible")
-        for item in items:
-            if "gpu" in item.keywords:
-                item.add_marker(skip)
+    if _gpu_present():
+        return
+    if "gpu" in expr:
+        raise pytest.UsageError("-m gpu was requested but no GPU is visible (torch.cuda.is_available() is False): "
+                                "the GPU parity tests cannot run here; use gpurun")
+    skip = pytest.mark.skip(reason="no GPU visible")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

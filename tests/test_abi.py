@@ -70,3 +70,13 @@ def test_generated_instruction_streams_are_current(tmp_path):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_gl_asm.py"), str(out)],
                           stderr=subprocess.DEVNULL)
     assert out.read_text() == open(os.path.join(ROOT, "ntt_aie_amd", "csrc", "gl_asm.h")).read()
+
+
+def test_product_library_reads_no_environment_and_has_no_experiment_paths(hiplib):
+    """Experiment knobs (NTT_DEBUG_FLAGS redirects loads / skips stores, NTT_FUSED, NTT_PLAN_SPLIT, NTT_TARGET_WGS*)
+    exist only in the -DNTT_EXPERIMENT build that tools/ load; the product .so must not even contain their names,
+    and the experimental fused launch must not be linked into it."""
+    blob = open(os.path.join(ROOT, "ntt_aie_amd", "libntt_hip.so"), "rb").read()
+    for name in (b"NTT_DEBUG_FLAGS", b"NTT_FUSED", b"NTT_PLAN_SPLIT", b"NTT_TARGET_WGS", b"fused_gl16"):
+        assert name not in blob, name
+    assert not os.path.exists(os.path.join(ROOT, "ntt_aie_amd", "csrc", "fused_gl16.hip"))

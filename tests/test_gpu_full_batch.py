@@ -1,0 +1,152 @@
+"""Parity at the REAL batch of every BASELINE.json configuration that fits one GPU, and of every pass kernel
+with a multi-iteration batch loop (ppw >= 2: counted-vmcnt LDS-DMA hand-off, double-buffered tiles).
+
+The batch changes `ppw`, `grid_y` and the loop counts of the pass kernels (pass.h:pass_geometry), which is
+exactly where an indexing bug would hide, so these cases run the C-ABI at full size and compare sampled rows
+word for word with the oracle plus size-independent properties over the WHOLE batch (round trip, coefficient
+sum).  Reference analogue of the word-exact check: src/test.cpp:203-235."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = 0xFFFFFFFF00000001
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    import ntt_aie_amd as E
+
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)
+    return E
+
+
+def _device_batch(torch, batch, n, p, wb, seed):
+    """Canonical residues generated on the device (host generation of 4 GiB would dominate the test)."""
+    g = torch.Generator(device="cuda:0").manual_seed(seed)
+    if wb == 8:
+        return torch.randint(0, 2**62, (batch, n), dtype=torch.int64, device="cuda:0", generator=g)  # < p
+    return torch.randint(0, p, (batch, n), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
+
+
+def _rowsum_mod_p(rows: np.ndarray, p: int) -> list:
+    return [int(r.astype(object).sum()) % p for r in rows]
+
+
+def test_config4_n20_batch512_forward_inverse_polymul(eng, oracle):
+    """BASELINE config 4 at its real batch: N = 2^20, Goldilocks, negacyclic (kind-2) table, batch 512.
+    ppw = 16 in the 512-thread LDS-DMA first pass, 8 in the column pass."""
+    import torch
+
+    p, logn, batch = GOLD, 20, 512
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, 8, 0)
+    T = pl.make_table(2, 7)
+    pl.set_twiddles(T)
+    assert pl.hbm_passes == 2
+    rows = [0, 1, 255, 256, 511]
+    a = _device_batch(torch, batch, n, p, 8, 2004)
+    ah = eng.to_host(a[rows])
+    f = pl.forward(a)
+    assert np.array_equal(eng.to_host(f[rows]), oracle.ntt(ah, T, p, nthreads=8)), "forward rows"
+    assert pl.count_noncanonical(f) == 0
+    # out[0] of every polynomial is its plain coefficient sum (every stage's x + y leg): the whole batch
+    col0 = eng.to_host(f[:, 0].contiguous())
+    sample = list(range(0, batch, 37))
+    assert [int(v) for v in col0[sample]] == _rowsum_mod_p(eng.to_host(a[sample]), p)
+    back = pl.inverse(f)
+    assert torch.equal(back, a), "inverse(forward) over the whole batch"
+    del back, f
+    # the product: rows {0, 511} against the oracle pipeline (unscaled inverse network on both operands,
+    # pointwise * N^-1, forward network: SURVEY F6-ii), plus linearity in the first operand over the whole batch
+    b = _device_batch(torch, batch, n, p, 8, 2005)
+    prow = [0, 511]
+    ah2, bh2 = eng.to_host(a[prow]), eng.to_host(b[prow])
+    A, B = oracle.intt(ah2, T, p, nthreads=8), oracle.intt(bh2, T, p, nthreads=8)
+    want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p, nthreads=8)
+    a2, b2 = a.clone(), b.clone()
+    c = pl.polymul_negacyclic(a2, b2)  # operands are scratch; result aliases a2
+    assert np.array_equal(eng.to_host(c[prow]), want), "polymul rows"
+    assert pl.count_noncanonical(c) == 0
+    # c[i][0] = a[i][0]*b[i][0] - sum_{j>=1} a[i][j]*b[i][N-j]: too costly for 512 rows on the host; instead the
+    # product with b = 1 (the constant polynomial) must return a, on the whole batch
+    one = torch.zeros_like(b)
+    one[:, 0] = 1
+    a3 = a.clone()
+    c1 = pl.polymul_negacyclic(a3, one)
+    assert torch.equal(c1, a), "a * 1 over the whole batch"
+
+
+def test_config5_per_gpu_shape_n16_batch8192(eng, oracle):
+    """BASELINE config 5's per-GPU shard: N = 2^16, Goldilocks, batch 8192 (4 GiB per buffer)."""
+    import torch
+
+    p, logn, batch = GOLD, 16, 8192
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, 8, 0)
+    T = pl.make_roots(7)
+    pl.set_twiddles(T)
+    x = _device_batch(torch, batch, n, p, 8, 5005)
+    X = pl.forward(x)
+    rows = [0, 1, 4095, 4096, 4097, 6000, 8190, 8191]
+    assert np.array_equal(eng.to_host(X[rows]), oracle.ntt(eng.to_host(x[rows]), T, p, nthreads=8))
+    assert pl.count_noncanonical(X) == 0
+    sample = list(range(0, batch, 257))
+    col0 = eng.to_host(X[:, 0].contiguous())
+    assert [int(v) for v in col0[sample]] == _rowsum_mod_p(eng.to_host(x[sample]), p)  # out[0] = sum(a)
+    assert torch.equal(pl.inverse(X), x)
+    # in place at the same batch
+    y = x.clone()
+    pl.forward(y, y)
+    assert torch.equal(y, X)
+
+
+@pytest.mark.parametrize("logn,batch", [(13, 8192), (14, 4096), (15, 2048), (17, 1024), (18, 512), (19, 256)])
+def test_multi_iteration_batch_loops_goldilocks(eng, oracle, logn, batch):
+    """Every Goldilocks first-pass kernel (256-thread LDS-DMA radix-8 for 7-9 stages, 512-thread one for 10-12) and
+    its non-DMA twin with the fused pointwise product, at a batch that makes the workgroups stream several polynomials
+    (ppw >= 4): forward, inverse, product -- sampled rows against the oracle, whole batch by round trip."""
+    import torch
+
+    p = GOLD
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, 8, 0)
+    T = pl.make_table(2, 7)
+    pl.set_twiddles(T)
+    a = _device_batch(torch, batch, n, p, 8, logn)
+    b = _device_batch(torch, batch, n, p, 8, logn + 100)
+    rows = [0, 1, batch // 2 - 1, batch // 2, batch - 2, batch - 1]
+    ah, bh = eng.to_host(a[rows]), eng.to_host(b[rows])
+    f = pl.forward(a)
+    assert np.array_equal(eng.to_host(f[rows]), oracle.ntt(ah, T, p, nthreads=8))
+    assert torch.equal(pl.inverse(f), a)
+    g = pl.inverse(a, scale=False)
+    assert np.array_equal(eng.to_host(g[rows]), oracle.pointwise(oracle.intt(ah, T, p, nthreads=8), np.ones_like(ah), p, n % p))
+    A, B = oracle.intt(ah, T, p, nthreads=8), oracle.intt(bh, T, p, nthreads=8)
+    want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p, nthreads=8)
+    c = pl.polymul_negacyclic(a.clone(), b.clone())
+    assert np.array_equal(eng.to_host(c[rows]), want)
+    one = torch.zeros_like(b)
+    one[:, 0] = 1
+    assert torch.equal(pl.polymul_negacyclic(a.clone(), one), a)
+
+
+@pytest.mark.parametrize("p,g", [(998244353, 3), (3221225473, 5)])
+@pytest.mark.parametrize("logn,batch", [(12, 65536), (16, 8192), (20, 256)])
+def test_multi_iteration_batch_loops_u32(eng, oracle, p, g, logn, batch):
+    """4-byte words (lazy p < 2^30 and carry-select p >= 2^31 streams) at batches with ppw >= 2 in every pass."""
+    import torch
+
+    n = 1 << logn
+    T = oracle.make_roots(n, p, g, 4)
+    pl = eng.NTTPlan(logn, p, 4, 0)
+    pl.set_twiddles(T)
+    a = _device_batch(torch, batch, n, p, 4, logn)
+    rows = [0, 1, batch // 2, batch - 1]
+    f = pl.forward(a)
+    assert np.array_equal(eng.to_host(f[rows]), oracle.ntt(eng.to_host(a[rows]), T, p, nthreads=4))
+    assert pl.count_noncanonical(f) == 0
+    assert torch.equal(pl.inverse(f), a)

@@ -296,34 +296,6 @@ def test_device_generated_tables(eng, oracle):
                 assert np.array_equal(eng.to_host(pl.inverse(f)), a)
 
 
-def test_fused_xcd_local_launch(eng, oracle, monkeypatch):
-    """Experimental NTT_FUSED=1 path (csrc/fused_gl16.hip): one persistent launch per transform,
-    column pass fed from the same XCD's L2, guarded by a device-side check + fallback.  Whatever the
-    dispatcher did, the stream-ordered result must equal the oracle's."""
-    from ntt_aie_amd import _lib
-
-    monkeypatch.setenv("NTT_FUSED", "1")
-    p, logn = GOLD, 16
-    n = 1 << logn
-    pl = eng.NTTPlan(logn, p, 8, 0)
-    T = pl.make_roots(7)
-    pl.set_twiddles(T)
-    assert _lib.lib().ntt_plan_info(pl._h, 5) == 1
-    for batch in (64, 136, 512):
-        a = _rand(batch, n, p, np.uint64, batch)
-        d = eng.to_device(a, "cuda:0")
-        out = pl.forward(d)
-        rows = list(range(0, batch, 7))
-        assert np.array_equal(eng.to_host(out[rows]), oracle.ntt(a[rows], T, p, nthreads=8)), batch
-        assert np.array_equal(eng.to_host(pl.inverse(out)), a)
-        ok = _lib.lib().ntt_plan_info(pl._h, 16 + 10)
-        done = _lib.lib().ntt_plan_info(pl._h, 16 + 9)
-        assert ok in (0, 1) and (ok == 0 or done == batch * 16)
-    # ineligible shapes silently take the two-launch path
-    b = _rand(5, n, p, np.uint64, 5)
-    assert np.array_equal(eng.to_host(pl.forward(eng.to_device(b, "cuda:0"))), oracle.ntt(b, T, p))
-
-
 def test_graph_capture_and_streams(eng, oracle):
     """The launch functions do no allocation or synchronisation, so a transform can be captured
     into a HIP graph and replayed, and runs on whatever stream the caller hands over."""

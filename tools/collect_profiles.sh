@@ -1,0 +1,36 @@
+#!/bin/bash
+# Collect the judged profile set of one build on the GPU box (run through gpurun from the repo root):
+#   tools/collect_profiles.sh r02
+# kernel-trace stats of the bench command, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate --pmc runs), SQ counters.
+# Everything lands under gpurun_out/prof_<tag>/ and the reduced summaries under gpurun_out/profiles_<tag>/ (copy the
+# latter into profiles/).  rocprofv3 gets `python3 bench.py ...` directly after `--` (no wrapper: the profiler's
+# preloaded library initialises the GPU before the program starts).
+set -eo pipefail
+TAG=${1:-r02}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+SUM=$ROOT/gpurun_out/profiles_$TAG
+mkdir -p "$OUT" "$SUM"
+export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH5="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+cd /tmp
+python3 $ROOT/bench.py > "$SUM/${TAG}_bench.json"
+tail -c 600 "$SUM/${TAG}_bench.json"; echo
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $BENCH > "$OUT/stats.log" 2>&1
+cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$SUM/${TAG}_kernel_stats.csv"
+echo "stats done"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o run -- $BENCH5 > "$OUT/fetch.log" 2>&1
+echo "fetch done"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o run -- $BENCH5 > "$OUT/write.log" 2>&1
+echo "write done"
+F=$(find "$OUT/fetch" -name '*counter_collection.csv' | head -1)
+W=$(find "$OUT/write" -name '*counter_collection.csv' | head -1)
+python3 $ROOT/tools/pmc_summary.py "$F" "$W" > "$SUM/${TAG}_pmc_traffic.json"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE \
+    --output-format csv -d "$OUT/sq" -o run -- $BENCH5 > "$OUT/sq.log" 2>&1
+echo "sq done"
+S=$(find "$OUT/sq" -name '*counter_collection.csv' | head -1)
+python3 $ROOT/tools/sq_summary.py "$S" > "$SUM/${TAG}_sq_counters.json"
+head -c 1500 "$SUM/${TAG}_pmc_traffic.json"; echo
+ls -la "$SUM"

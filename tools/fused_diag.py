@@ -1,9 +1,11 @@
 """Diagnostics for the experimental fused launch (NTT_FUSED=1): correctness on sampled rows, time per
 step and the control words of the last launch (slots per XCC, status, completed column tiles, verdict).
-NTT_DEBUG_FLAGS=16/32/64 isolate the roles (see csrc/fused_gl16.hip).  Usage: fused_diag.py BATCH"""
+NTT_DEBUG_FLAGS=16/32/64 isolate the roles (see tools/fused_gl16.hip).  Usage: fused_diag.py BATCH"""
 import os, sys, time, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+# experiment knobs live only in libntt_hip_exp.so (make -C ntt_aie_amd/csrc exp): the product library reads no env
+os.environ.setdefault("NTT_HIP_LIB", os.path.join(ROOT, "ntt_aie_amd", "libntt_hip_exp.so"))
 os.environ["NTT_FUSED"] = "1"
 import torch, oracle_py as O
 from ntt_aie_amd import NTTPlan, to_device, to_host

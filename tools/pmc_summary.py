@@ -2,13 +2,16 @@
 """Reduce rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection.csv files (separate passes, as
 MI355X_MICROARCH.md's HBM section prescribes) to HBM bytes per launch of each pass kernel.
 
-usage: pmc_summary.py <bench_fetch.csv> <bench_write.csv> [<calib_fetch.csv> <calib_write.csv>] > r01_pmc_traffic.json
+usage: pmc_summary.py <bench_fetch.csv> <bench_write.csv> [<calib_fetch.csv> <calib_write.csv>] > profiles/rNN_pmc_traffic.json
 
 Units: both counters are KiB.  gfx950 correction: FETCH_SIZE counts half of the bytes read (the calibration
 copies of tools/pmc_calib.hip show it: 1 GiB copied reads 0.5 GiB by the counter), so it is doubled;
 WRITE_SIZE is exact."""
-import csv, json, sys
+import csv, json, os, sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ntt_aie_amd._lib import kernel_source_hash  # the kernels these counters belong to (bench.py checks it)
 
 
 def per_kernel(path, counter):
@@ -29,7 +32,8 @@ def short(name):
 
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; unit KiB; FETCH_SIZE doubled "
+    out = {"src_hash": kernel_source_hash(),
+           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; unit KiB; FETCH_SIZE doubled "
                    "(gfx950 correction, confirmed by tools/pmc_calib.hip), WRITE_SIZE exact; launches with the "
                    "largest grid of each kernel only (the timed batch, not the parity smoke)",
            "kernels": {}}
