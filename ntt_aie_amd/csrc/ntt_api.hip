@@ -542,10 +542,18 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
     // With the Longa-Naehrig psi^-1 table the forward negacyclic NTT is the UNSCALED
     // inverse network and the inverse negacyclic NTT is N^-1 * forward network
     // (SURVEY F6-ii), so  c = Fwd( InvU(a) . InvU(b) . N^-1 ).
-    rc = run_inverse(pl, d_a, d_a, batch, NTT_LAYOUT_NATURAL, 0, s);
-    if (rc) return rc;
-    rc = run_inverse(pl, d_b, d_b, batch, NTT_LAYOUT_NATURAL, 0, s);
-    if (rc) return rc;
+    const size_t operand_bytes = (batch << pl->logn) * (size_t) pl->word_bytes;
+    if ((const char *) d_b == (const char *) d_a + operand_bytes && 2 * batch <= 0x7FFFFFFFull) {
+        // the operands are one [2*batch][N] buffer: both unscaled inverse transforms as ONE launch per pass
+        // (half the launches, twice the polynomials streamed through each workgroup's resident twiddles)
+        rc = run_inverse(pl, d_a, d_a, 2 * batch, NTT_LAYOUT_NATURAL, 0, s);
+        if (rc) return rc;
+    } else {
+        rc = run_inverse(pl, d_a, d_a, batch, NTT_LAYOUT_NATURAL, 0, s);
+        if (rc) return rc;
+        rc = run_inverse(pl, d_b, d_b, batch, NTT_LAYOUT_NATURAL, 0, s);
+        if (rc) return rc;
+    }
     // pointwise product * N^-1 folded into the first pass of the final forward transform
     return run_forward(pl, d_a, d_out, batch, NTT_LAYOUT_NATURAL, s, d_b, pl->ninv_plain);
 }

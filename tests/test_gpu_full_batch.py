@@ -129,6 +129,11 @@ def test_multi_iteration_batch_loops_goldilocks(eng, oracle, logn, batch):
     want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p, nthreads=8)
     c = pl.polymul_negacyclic(a.clone(), b.clone())
     assert np.array_equal(eng.to_host(c[rows]), want)
+    # the operands as ONE [2*batch][N] buffer: the library transforms both with one launch per pass
+    ab = torch.cat([a, b])
+    c2 = pl.polymul_negacyclic(ab[:batch], ab[batch:])
+    assert c2.data_ptr() == ab.data_ptr() and torch.equal(c2, c)
+    del ab, c2
     one = torch.zeros_like(b)
     one[:, 0] = 1
     assert torch.equal(pl.polymul_negacyclic(a.clone(), one), a)

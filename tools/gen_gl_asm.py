@@ -8,7 +8,7 @@ needs two other instructions in between (the compiler pads with s_nop), and hipc
 butterfly is 24 VALU instructions when written with v_add_co/v_addc_co/v_subb_co chains:
 
   sub   d = x - y (mod p)                    4 VALU + 1 SALU
-  mul   r = d * T  (T in Montgomery form)    4 v_mad_u64_u32 + 10 VALU + 1 SALU
+  mul   r = d * T  (T in Montgomery form)    4 v_mad_u64_u32 + 10 VALU + 1 SALU (9: the zero half of one addend is a pinned register)
   add   s = x + y (mod p)                    6 VALU + 1 SALU
 
 The two butterflies' instructions are merged by a list scheduler that keeps every
@@ -91,7 +91,8 @@ def butterfly(kind, b, vbase=104):
         # (m1:m0) * (t1:t0) * 2^-64 mod p, canonical; m may be any 64-bit value
         ins.append(Ins(f"v_mad_u64_u32 {P(L)}, vcc, {m0}, {t0}, 0", [m0, t0], [L[0], L[1], "vcc"]))
         ins.append(Ins(f"v_mov_b32 {A[0]}, {L[1]}", [L[1]], [A[0]]))
-        ins.append(Ins(f"v_mov_b32 {A[1]}, 0", [], [A[1]]))
+        # A[1] holds zero for the whole kernel: a register-pinned variable handed to the statement as an INPUT (emit()),
+        # so the compiler materialises it once outside the batch loop instead of one v_mov per butterfly
         ins.append(Ins(f"v_mad_u64_u32 {P(M)}, vcc, {m0}, {t1}, {P(A)}", [m0, t1, A[0], A[1]], [M[0], M[1], "vcc"]))
         ins.append(Ins(f"v_mad_u64_u32 {P(M)}, {sa}, {m1}, {t0}, {P(M)}", [m1, t0, M[0], M[1]], [M[0], M[1], sa]))
         ins.append(Ins(f"v_mov_b32 {B[0]}, {M[1]}", [M[1]], [B[0]]))
@@ -312,6 +313,12 @@ def emit(kind, nb, tw_constraint, vbase=104, suffix=""):
         src.append(f"    const uint32_t t0_{b} = (uint32_t) t{b}, t1_{b} = (uint32_t) (t{b} >> 32);")
         if kind != "mul":
             src.append(f"    uint32_t d0_{b}, d1_{b};")
+    zero_regs = [vbase + 12 * b + 5 for b in range(nb)]  # A[1] of every butterfly slot
+    for b, r in enumerate(zero_regs):
+        # defined by an (identical, side-effect-free) asm so that the compiler merges the definitions of all
+        # butterflies into one and cannot re-materialise the constant in front of every statement
+        src.append(f"    register uint32_t zero_{b} asm(\"v{r}\");  // high half of the 64-bit addend {{x, 0}} of v_mad_u64_u32")
+        src.append(f"    asm(\"v_mov_b32 %0, 0\" : \"=v\"(zero_{b}));")
     src.append("    asm volatile(")
     for l in lines:
         src.append(f'        "{l}\\n\\t"')
@@ -324,7 +331,8 @@ def emit(kind, nb, tw_constraint, vbase=104, suffix=""):
         ins_ += [f'[t0_{b}] "{tw_constraint}"(t0_{b})', f'[t1_{b}] "{tw_constraint}"(t1_{b})']
     if kind == "fwd":
         ins_ += ['[pp] "s"(0xFFFFFFFF00000001ull)']  # p, for the 64-bit compare of the modular add
-    clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 12 * nb)] + [f'"s{r}"' for r in range(84, 84 + 8 * nb)]
+    ins_ += [f'[zero_{b}] "v"(zero_{b})' for b in range(nb)]
+    clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 12 * nb) if r not in zero_regs] + [f'"s{r}"' for r in range(84, 84 + 8 * nb)]
     src.append("        : " + ", ".join(outs))
     src.append("        : " + ", ".join(ins_))
     src.append("        : " + ", ".join(clob) + ");")
