@@ -20,6 +20,7 @@ struct ErasedArgs {
     uint64_t scale;  // table form
     uint32_t target_wgs;
     int dbg;  // timing experiments (NTT_DEBUG_FLAGS), 0 in production
+    const void *tw2;     // product_mid launch: the FORWARD table (tw is the inverse one there)
     const void *in2;     // forward CONTIG pass: second operand of a fused pointwise product (or null)
     uint64_t pw_scale;   // scale * R^2 (see PassArgs::pw_scale)
     const void *skip_if;  // experiment build only: device word, non-zero = the launch is a no-op (fallback behind the fused kernel)
@@ -31,6 +32,12 @@ hipError_t launch_gl_fwd(bool contig, int log_m, const ErasedArgs &a, hipStream_
 hipError_t launch_gl_inv(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
 hipError_t launch_m32_fwd(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
 hipError_t launch_m32_inv(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
+
+// Fused middle of a negacyclic product (pass.h: run_product_pass): per 2^log_m-word unit, inverse CONTIG pass of a.in
+// and of a.in2, word-by-word product * pw_scale, forward CONTIG pass -> a.out.  tw = inverse table, tw2 = forward table.
+// hipErrorInvalidValue when this (word size, log_m) has no fused kernel (callers then run the separate passes).
+hipError_t launch_gl_product_mid(int log_m, const ErasedArgs &a, hipStream_t s);
+bool have_gl_product_mid(int log_m);
 
 #if defined(NTT_EXPERIMENT)
 // Tools-side experiment, NOT part of libntt_hip.so (tools/fused_gl16.hip, libntt_hip_exp.so only):

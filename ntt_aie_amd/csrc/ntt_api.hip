@@ -543,9 +543,51 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
     // inverse network and the inverse negacyclic NTT is N^-1 * forward network
     // (SURVEY F6-ii), so  c = Fwd( InvU(a) . InvU(b) . N^-1 ).
     const size_t operand_bytes = (batch << pl->logn) * (size_t) pl->word_bytes;
-    if ((const char *) d_b == (const char *) d_a + operand_bytes && 2 * batch <= 0x7FFFFFFFull) {
+    const bool contiguous = (const char *) d_b == (const char *) d_a + operand_bytes && 2 * batch <= 0x7FFFFFFFull;
+    const PassDesc &first = pl->passes.front();
+    const bool fused_mid = pl->word_bytes == 8 && pl->passes.size() >= 2 && first.contig &&
+                           ntt::contig_log_e(first.log_m, 8, false) == 3 && ntt::have_gl_product_mid(first.log_m);
+    if (fused_mid) {
+        // Multi-pass Goldilocks sizes: the column passes of both unscaled inverse transforms, then ONE launch that runs
+        // the last inverse pass of a and of b, the pointwise product * N^-1 and the first forward pass on each
+        // 2^log_m-word unit while it is workgroup-resident (3 N words of HBM traffic instead of 7 N), then the
+        // forward column passes.
+        for (size_t i = pl->passes.size(); i-- > 1;) {
+            const PassDesc &pd = pl->passes[i];
+            RoctxRange pass("product: inv pass", pd.contig, pd.s0, pd.log_m);
+            for (int op = 0; op < (contiguous ? 1 : 2); op++) {
+                void *buf = op == 0 ? d_a : d_b;
+                ntt::ErasedArgs a = base_args(pl, pd, buf, buf, contiguous ? 2 * batch : batch);
+                a.tw = pl->d_tw_inv;
+                a.layout = NTT_LAYOUT_NATURAL;
+                hipError_t e = ntt::launch_gl_inv(pd.contig, pd.log_m, a, s);
+                if (e != hipSuccess) return (int) e;
+            }
+        }
+        {
+            RoctxRange pass("product: fused middle", 1, 0, first.log_m);
+            ntt::ErasedArgs a = base_args(pl, first, d_a, d_out, batch);
+            a.in2 = d_b;
+            a.tw = pl->d_tw_inv;
+            a.tw2 = pl->d_tw_fwd;
+            a.layout = NTT_LAYOUT_NATURAL;
+            a.pw_scale = to_table_form(to_table_form(pl->ninv_plain % pl->p, pl->p, 8), pl->p, 8);
+            hipError_t e = ntt::launch_gl_product_mid(first.log_m, a, s);
+            if (e != hipSuccess) return (int) e;
+        }
+        for (size_t i = 1; i < pl->passes.size(); i++) {
+            const PassDesc &pd = pl->passes[i];
+            RoctxRange pass("product: fwd pass", pd.contig, pd.s0, pd.log_m);
+            ntt::ErasedArgs a = base_args(pl, pd, d_out, d_out, batch);
+            a.tw = pl->d_tw_fwd;
+            a.layout = NTT_LAYOUT_NATURAL;
+            hipError_t e = ntt::launch_gl_fwd(pd.contig, pd.log_m, a, s);
+            if (e != hipSuccess) return (int) e;
+        }
+        return NTT_OK;
+    }
+    if (contiguous) {
         // the operands are one [2*batch][N] buffer: both unscaled inverse transforms as ONE launch per pass
-        // (half the launches, twice the polynomials streamed through each workgroup's resident twiddles)
         rc = run_inverse(pl, d_a, d_a, 2 * batch, NTT_LAYOUT_NATURAL, 0, s);
         if (rc) return rc;
     } else {

@@ -589,12 +589,13 @@ NTT_HD void phase_lds_write(Ctx<Cfg> &c, typename Cfg::W *lds) {
 // M32_MODE: which 4-byte-word instruction stream runs (0 lazy p < 2^30, 1 p < 2^31, 2 any); -1 = decide here from
 // the kernel argument.  The GPU kernels decide ONCE, around the whole pass (pass_kernel.inc): a branch per asm
 // statement made hipcc reconcile the register assignment of the three arms with ~250 v_mov per polynomial.
-template <class Cfg, int r, int M32_MODE = -1>
+// TW_READY: the caller has already put this round's twiddles into c.tw[r] (run_product_pass reads them from an LDS table)
+template <class Cfg, int r, int M32_MODE = -1, bool TW_READY = false>
 NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
     using W = typename Cfg::W;
     constexpr int b0 = Cfg::win(r);
     constexpr int lo = Cfg::stage_lo(r), hi = Cfg::stage_hi(r);
-    if constexpr (!Cfg::preload(r)) load_twiddles<Cfg, r>(c, a);
+    if constexpr (!Cfg::preload(r) && !TW_READY) load_twiddles<Cfg, r>(c, a);
     const typename Cfg::F &f = a.field;
     static_for<0, hi - lo>([&](auto kk) {
         constexpr int m = Cfg::INV ? (hi - 1 - decltype(kk)::value) : (lo + decltype(kk)::value);
@@ -819,6 +820,134 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         }
     }
     ex.pass_done(completed);
+}
+
+// Twiddles of the rounds that are neither resident (PRELOAD_MASK) nor wave-uniform, for the product pass: a workgroup
+// keeps its (hi-block, round) twiddles in a small LDS table -- a round whose window starts at bit b0 has one set of
+// E-1 twiddles per 2^b0 consecutive threads, (NT >> b0) sets in all -- filled once per workgroup and read back at the
+// start of the round (no address registers, LDS latency instead of L2 latency).
+template <class Cfg>
+constexpr int tw_table_offset(int r) {  // words in front of round r's sets
+    int off = 0;
+    for (int k = 0; k < r; ++k)
+        if (!Cfg::preload(k)) off += (Cfg::E - 1) * (Cfg::NT >> Cfg::win(k));
+    return off;
+}
+template <class Cfg>
+constexpr int tw_table_words() { return tw_table_offset<Cfg>(Cfg::R) > 0 ? tw_table_offset<Cfg>(Cfg::R) : 1; }
+
+template <class Cfg, int r>
+NTT_HD void tw_table_fill(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *table) {
+    static_assert(Cfg::LOG_C == 0, "CONTIG tiles only");
+    constexpr int b0 = Cfg::win(r);
+#pragma unroll
+    for (int k = 0; k < Cfg::E - 1; ++k) c.tw[r][k] = 0;
+    load_twiddles<Cfg, r>(c, a);
+    if ((c.tid & ((1u << b0) - 1u)) == 0) {
+        typename Cfg::W *p = table + tw_table_offset<Cfg>(r) + (c.tid >> b0) * (Cfg::E - 1);
+#pragma unroll
+        for (int k = 0; k < Cfg::E - 1; ++k) p[k] = c.tw[r][k];
+    }
+}
+template <class Cfg, int r>
+NTT_HD void tw_table_read(Ctx<Cfg> &c, const typename Cfg::W *table) {
+    constexpr int b0 = Cfg::win(r);
+    const typename Cfg::W *p = table + tw_table_offset<Cfg>(r) + (c.tid >> b0) * (Cfg::E - 1);
+#pragma unroll
+    for (int k = 0; k < Cfg::E - 1; ++k) c.tw[r][k] = p[k];
+}
+
+// ---- fused middle of a negacyclic product ---------------------------------------
+// c = Fwd( InvU(a) . InvU(b) . N^-1 ): the LAST pass of both unscaled inverse transforms and the FIRST pass of the
+// forward transform are CONTIG passes over the same 2^LOG_M-word units, and an inverse CONTIG pass ends in exactly
+// the register layout a forward one begins with (round 0: a thread owns E consecutive words).  So one workgroup
+// runs, per unit:  load a -> inverse stages LOG_M-1..0 -> keep in registers;  load b -> the same;  multiply word by
+// word (* N^-1);  forward stages 0..LOG_M-1 -> store.  HBM traffic of the product's middle: 3 N words (read a, read b,
+// write c) instead of 7 N (two inverse passes 2 N each, product + first forward pass 3 N).
+// CI = the inverse CONTIG configuration, CF = the forward one (non-DMA), same LOG_M / LOG_E / LOG_NT.
+// Exec: eachI(fn(Ctx<CI>&)), eachF(fn(Ctx<CF>&)), eachIF(fn(Ctx<CI>&, Ctx<CF>&, W *keep)), sync(), lds(), pg_base(),
+// tabI() / tabF(): the LDS twiddle tables of the two directions (tw_table_words<C>() words each).
+template <class CI, class CF, class Exec>
+NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI> &ab, const PassArgs<CF> &af) {
+    using W = typename CI::W;
+    static_assert(CI::CONTIG && CF::CONTIG && CI::INV && !CF::INV, "middle of the product: inverse CONTIG then forward CONTIG");
+    static_assert(CI::LOG_M == CF::LOG_M && CI::LOG_E == CF::LOG_E && CI::LOG_NT == CF::LOG_NT && CI::R == CF::R, "same tile");
+    static_assert(CI::DIRECT_LOAD && CF::DIRECT_STORE && !CF::DMA && CI::R > 1, "register <-> HBM at both ends");
+    constexpr int R = CI::R;
+    using WL = std::integral_constant<bool, CI::WAVE_LOCAL>;
+    ex.init(aa, af);
+    static_for<0, R>([&](auto rr) {  // fill the LDS twiddle tables (once per workgroup: its hi-block is fixed)
+        constexpr int r = decltype(rr)::value;
+        if constexpr (!CI::preload(r)) ex.eachI([&](Ctx<CI> &c) { tw_table_fill<CI, r>(c, aa, ex.tabI()); });
+        if constexpr (!CF::preload(r)) ex.eachF([&](Ctx<CF> &c) { tw_table_fill<CF, r>(c, af, ex.tabF()); });
+    });
+    ex.sync(std::false_type{});
+    auto group_valid = [&](int it) {
+        return it < aa.ppw && (((uint64_t) ex.pg_base() + (uint64_t) it) << aa.log_up) < aa.batch;
+    };
+    auto inverse_unit = [&](const PassArgs<CI> &a, int it, W *tile) {
+        wave_prio(NTT_SETPRIO & 1);
+        ex.eachI([&](Ctx<CI> &c) { phase_load_direct<CI, R - 1>(c, a, it); });
+        wave_prio(0);
+        static_for<0, R>([&](auto kk) {
+            constexpr int r = R - 1 - decltype(kk)::value;
+            if constexpr (!CI::preload(r)) ex.eachI([&](Ctx<CI> &c) { tw_table_read<CI, r>(c, ex.tabI()); });
+            ex.eachI([&](Ctx<CI> &c) { phase_compute<CI, r, -1, true>(c, a); });
+            if constexpr (r > 0) {
+                ex.eachI([&](Ctx<CI> &c) { phase_lds_write<CI, r>(c, tile); });
+                ex.sync(WL{});
+                ex.eachI([&](Ctx<CI> &c) { phase_lds_read<CI, r - 1>(c, tile); });
+            }
+        });
+    };
+    for (int it = 0; it < aa.ppw; ++it) {
+        if (!group_valid(it)) break;
+        W *const tile = ex.lds();
+        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &cf, W *) {
+            phase_begin_iter<CI>(ci, aa, it);
+            cf.active = ci.active;
+        });
+        inverse_unit(aa, it, tile);
+        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *keep) {
+#pragma unroll
+            for (int e = 0; e < CI::E; ++e) keep[e] = ci.x[e];
+        });
+        ex.sync(WL{});  // every wave has read its round-0 words: the tile may be rewritten
+        inverse_unit(ab, it, tile);
+        // word-by-word product * N^-1.  Both factors are arbitrary 64-bit representatives (the inverse butterflies
+        // carry lazy sums): the first product is then a correct 64-bit representative, the second one (by the
+        // canonical constant pw_scale) is canonical -- no canonicalisation pass in between.
+        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &cf, W *keep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if constexpr (std::is_same<typename CI::F, FieldGL>::value && CI::E >= 2 && CI::LOG_E < 4) {
+                static_for<0, CI::E / 2>([&](auto pp) {
+                    constexpr int e = 2 * decltype(pp)::value;
+                    gl_mul2_v_lo(keep[e], ci.x[e], keep[e + 1], ci.x[e + 1]);
+                    gl_mul2_v_lo(keep[e], af.pw_scale, keep[e + 1], af.pw_scale);
+                    cf.x[e] = keep[e];
+                    cf.x[e + 1] = keep[e + 1];
+                });
+                return;
+            }
+#endif
+#pragma unroll
+            for (int e = 0; e < CI::E; ++e) cf.x[e] = af.field.mul(af.field.mul(keep[e], ci.x[e]), af.pw_scale);
+        });
+        ex.sync(WL{});
+        static_for<0, R>([&](auto kk) {
+            constexpr int r = decltype(kk)::value;
+            if constexpr (!CF::preload(r)) ex.eachF([&](Ctx<CF> &c) { tw_table_read<CF, r>(c, ex.tabF()); });
+            ex.eachF([&](Ctx<CF> &c) { phase_compute<CF, r, -1, true>(c, af); });
+            if constexpr (r < R - 1) {
+                ex.eachF([&](Ctx<CF> &c) { phase_lds_write<CF, r>(c, tile); });
+                ex.sync(WL{});
+                ex.eachF([&](Ctx<CF> &c) { phase_lds_read<CF, r + 1>(c, tile); });
+            }
+        });
+        ex.eachF([&](Ctx<CF> &c) { phase_canon<CF>(c, af); });
+        ex.eachF([&](Ctx<CF> &c) { phase_store_direct<CF, R - 1>(c, af, it); });
+        // ... and none here: the next unit's first LDS write goes to the round R-1 positions this thread read last
+    }
 }
 
 // ---- launch geometry shared by host planner and host model ---------------------

@@ -1,0 +1,5 @@
+import sys, os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/tools")
+import bench_configs as B
+B.run("cfg4: N=2^20, Goldilocks, batch 512, negacyclic polymul", 20, B.GOLD, 7, 8, 512, kind=2, polymul=True)
+B.run("N=2^16 polymul batch 4096", 16, B.GOLD, 7, 8, 4096, kind=2, polymul=True)

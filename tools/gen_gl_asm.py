@@ -356,6 +356,10 @@ def main():
             out.append(txt)
             out.append("")
             print(f"{kind} x2 tw={tw}: {n} instructions, {nops} nops", file=sys.stderr)
+        if kind == "mul":  # product of two data words inside the light kernels (fused polynomial product)
+            txt, n, nops = emit(kind, 2, "v", vbase=72, suffix="_lo")
+            out.append(txt)
+            out.append("")
         if kind != "mul":
             for tw in ("v", "s"):  # for the radix-8 (light) kernels: scratch lives lower
                 for vb, sfx in ((72, "_lo"), (56, "_lo2")):
