@@ -16,6 +16,7 @@ struct GpuProductExec {
     Ctx<CI> ci;
     Ctx<CF> cf;
     W keep[CI::E];  // the transformed words of operand a while operand b is transformed
+    W pre[CI::E];   // register prefetch: operand b of this unit / operand a of the next one
     W *tile, *tab_i, *tab_f;
     __device__ __forceinline__ void init(const PassArgs<CI> &aa, const PassArgs<CF> &af) {
         phase_init<CI>(ci, aa, threadIdx.x, blockIdx.x, blockIdx.y);
@@ -26,7 +27,7 @@ struct GpuProductExec {
     template <class Fn>
     __device__ __forceinline__ void eachF(Fn &&f) { f(cf); }
     template <class Fn>
-    __device__ __forceinline__ void eachIF(Fn &&f) { f(ci, cf, keep); }
+    __device__ __forceinline__ void eachIF(Fn &&f) { f(ci, cf, keep, pre); }
     __device__ __forceinline__ void sync(std::false_type) { __syncthreads(); }
     __device__ __forceinline__ void sync(std::true_type) {  // wave-local unit: LDS operations of one wave execute in order
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -47,6 +47,9 @@
 #ifndef NTT_LATE_SYNC
 #define NTT_LATE_SYNC 0  // experiment knob: end-of-iteration barrier moved to before the next iteration's first LDS write (measured: column pass +2 %, worse)
 #endif
+#ifndef NTT_PRODUCT_PREFETCH_A
+#define NTT_PRODUCT_PREFETCH_A 0  // product pass: also prefetch the NEXT unit's operand a during the forward rounds (b is always prefetched)
+#endif
 #ifndef NTT_INV_PREFETCH
 #define NTT_INV_PREFETCH 0  // experiment knob: register prefetch in the inverse CONTIG radix-8 passes (measured: no gain)
 #endif
@@ -392,10 +395,11 @@ __device__ __forceinline__ void buf_store(W v, __amdgpu_buffer_rsrc_t rs, uint32
 }
 #endif
 
-template <class Cfg, int r, bool NEXT = false>
-NTT_HD void phase_load_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
+// loads the E words of round r's window of iteration `it` into dstx (c.x, the prefetch set c.xn, or a caller's array);
+// `active`: whether this lane's polynomial of that iteration exists (ragged batch tail)
+template <class Cfg, int r>
+NTT_HD void phase_load_direct_to(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it, typename Cfg::W *dstx, bool active) {
     using W = typename Cfg::W;
-    W *const dstx = NEXT ? c.xn : c.x;
     const W *ubase = a.in + uniform_word<Cfg>(c, a, it);
 #if defined(__HIP_DEVICE_COMPILE__)
     // element offsets stay below 2^32 bytes: (E-1) << (n - LOG_E) words at most
@@ -405,7 +409,7 @@ NTT_HD void phase_load_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     for (int e = 0; e < Cfg::E; ++e) {
         const uint32_t so = (elem_eff<Cfg>(a, e, Cfg::INV) << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W);
         dstx[e] = (W) 0;
-        if (c.active) dstx[e] = buf_load<W>(rs, voff, so);
+        if (active) dstx[e] = buf_load<W>(rs, voff, so);
     }
     if (Cfg::CONTIG && !Cfg::INV && a.in2 != nullptr) {
         const __amdgpu_buffer_rsrc_t rs2 =
@@ -413,18 +417,23 @@ NTT_HD void phase_load_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
 #pragma unroll
         for (int e = 0; e < Cfg::E; ++e) {
             const uint32_t so = ((uint32_t) e << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W);
-            if (c.active) dstx[e] = a.field.mul(a.field.mul(dstx[e], buf_load<W>(rs2, voff, so)), a.pw_scale);
+            if (active) dstx[e] = a.field.mul(a.field.mul(dstx[e], buf_load<W>(rs2, voff, so)), a.pw_scale);
         }
     }
 #else
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
         const size_t eo = (size_t) elem_eff<Cfg>(a, e, Cfg::INV) << (Cfg::win(r) + a.s0);
-        dstx[e] = c.active ? (ubase + eo)[c.lane_ld] : (W) 0;
-        if (Cfg::CONTIG && !Cfg::INV && a.in2 != nullptr && c.active)
+        dstx[e] = active ? (ubase + eo)[c.lane_ld] : (W) 0;
+        if (Cfg::CONTIG && !Cfg::INV && a.in2 != nullptr && active)
             dstx[e] = a.field.mul(a.field.mul(dstx[e], (a.in2 + uniform_word<Cfg>(c, a, it) + eo)[c.lane_ld]), a.pw_scale);
     }
 #endif
+}
+
+template <class Cfg, int r, bool NEXT = false>
+NTT_HD void phase_load_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
+    phase_load_direct_to<Cfg, r>(c, a, it, NEXT ? c.xn : c.x, c.active);
 }
 
 template <class Cfg, int r>
@@ -865,7 +874,7 @@ NTT_HD void tw_table_read(Ctx<Cfg> &c, const typename Cfg::W *table) {
 // word (* N^-1);  forward stages 0..LOG_M-1 -> store.  HBM traffic of the product's middle: 3 N words (read a, read b,
 // write c) instead of 7 N (two inverse passes 2 N each, product + first forward pass 3 N).
 // CI = the inverse CONTIG configuration, CF = the forward one (non-DMA), same LOG_M / LOG_E / LOG_NT.
-// Exec: eachI(fn(Ctx<CI>&)), eachF(fn(Ctx<CF>&)), eachIF(fn(Ctx<CI>&, Ctx<CF>&, W *keep)), sync(), lds(), pg_base(),
+// Exec: eachI(fn(Ctx<CI>&)), eachF(fn(Ctx<CF>&)), eachIF(fn(Ctx<CI>&, Ctx<CF>&, W *keep, W *pre)), sync(), lds(), pg_base(),
 // tabI() / tabF(): the LDS twiddle tables of the two directions (tw_table_words<C>() words each).
 template <class CI, class CF, class Exec>
 NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI> &ab, const PassArgs<CF> &af) {
@@ -885,10 +894,10 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
     auto group_valid = [&](int it) {
         return it < aa.ppw && (((uint64_t) ex.pg_base() + (uint64_t) it) << aa.log_up) < aa.batch;
     };
-    auto inverse_unit = [&](const PassArgs<CI> &a, int it, W *tile) {
-        wave_prio(NTT_SETPRIO & 1);
-        ex.eachI([&](Ctx<CI> &c) { phase_load_direct<CI, R - 1>(c, a, it); });
-        wave_prio(0);
+    auto lane_active = [&](const Ctx<CI> &c, int it) {  // does this lane's polynomial of iteration `it` exist
+        return CI::LOG_U == 0 ? true : ((((c.pg_base + (uint32_t) it) << aa.log_up) | c.up) < aa.batch);
+    };
+    auto inverse_unit = [&](const PassArgs<CI> &a, W *tile) {  // on the words already in ci.x
         static_for<0, R>([&](auto kk) {
             constexpr int r = R - 1 - decltype(kk)::value;
             if constexpr (!CI::preload(r)) ex.eachI([&](Ctx<CI> &c) { tw_table_read<CI, r>(c, ex.tabI()); });
@@ -900,24 +909,44 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
             }
         });
     };
+    // Register prefetch: operand b is fetched while operand a is transformed, and the next unit's operand a while this
+    // unit's product is transformed forward; the three data sets (working words, kept transform of a, prefetch) are
+    // never live together, 2 x E words at any time.
+    if (NTT_PRODUCT_PREFETCH_A && group_valid(0)) {
+        wave_prio(NTT_SETPRIO & 1);
+        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *, W *pre) { phase_load_direct_to<CI, R - 1>(ci, aa, 0, pre, lane_active(ci, 0)); });
+        wave_prio(0);
+    }
     for (int it = 0; it < aa.ppw; ++it) {
         if (!group_valid(it)) break;
         W *const tile = ex.lds();
-        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &cf, W *) {
+        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &cf, W *, W *pre) {
             phase_begin_iter<CI>(ci, aa, it);
             cf.active = ci.active;
-        });
-        inverse_unit(aa, it, tile);
-        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *keep) {
+            if (NTT_PRODUCT_PREFETCH_A) {
 #pragma unroll
-            for (int e = 0; e < CI::E; ++e) keep[e] = ci.x[e];
+                for (int e = 0; e < CI::E; ++e) ci.x[e] = pre[e];
+            } else {
+                phase_load_direct_to<CI, R - 1>(ci, aa, it, ci.x, ci.active);
+            }
+        });
+        wave_prio(NTT_SETPRIO & 1);
+        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *, W *pre) { phase_load_direct_to<CI, R - 1>(ci, ab, it, pre, ci.active); });
+        wave_prio(0);
+        inverse_unit(aa, tile);
+        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *keep, W *pre) {
+#pragma unroll
+            for (int e = 0; e < CI::E; ++e) {
+                keep[e] = ci.x[e];
+                ci.x[e] = pre[e];
+            }
         });
         ex.sync(WL{});  // every wave has read its round-0 words: the tile may be rewritten
-        inverse_unit(ab, it, tile);
+        inverse_unit(ab, tile);
         // word-by-word product * N^-1.  Both factors are arbitrary 64-bit representatives (the inverse butterflies
         // carry lazy sums): the first product is then a correct 64-bit representative, the second one (by the
         // canonical constant pw_scale) is canonical -- no canonicalisation pass in between.
-        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &cf, W *keep) {
+        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &cf, W *keep, W *) {
 #if defined(__HIP_DEVICE_COMPILE__)
             if constexpr (std::is_same<typename CI::F, FieldGL>::value && CI::E >= 2 && CI::LOG_E < 4) {
                 static_for<0, CI::E / 2>([&](auto pp) {
@@ -933,7 +962,12 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
 #pragma unroll
             for (int e = 0; e < CI::E; ++e) cf.x[e] = af.field.mul(af.field.mul(keep[e], ci.x[e]), af.pw_scale);
         });
-        ex.sync(WL{});
+        if (NTT_PRODUCT_PREFETCH_A && group_valid(it + 1)) {
+            wave_prio(NTT_SETPRIO & 1);
+            ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *, W *pre) { phase_load_direct_to<CI, R - 1>(ci, aa, it + 1, pre, lane_active(ci, it + 1)); });
+            wave_prio(0);
+        }
+        // no barrier here: the forward rounds first WRITE the round-0 positions, which this thread itself read last
         static_for<0, R>([&](auto kk) {
             constexpr int r = decltype(kk)::value;
             if constexpr (!CF::preload(r)) ex.eachF([&](Ctx<CF> &c) { tw_table_read<CF, r>(c, ex.tabF()); });
