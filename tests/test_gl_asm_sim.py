@@ -1,0 +1,117 @@
+"""The generated gfx950 instruction streams of csrc/gl_asm.h, executed one lane at a time by the generator's own
+interpreter (tools/gen_gl_asm.py: simulate) and checked against plain Python integers: random words plus the edge
+residues / twiddles that drive every carry, borrow and correction path.  No GPU needed; the GPU parity tests then
+show that the hardware agrees with this reading of the instructions."""
+import importlib.util
+import os
+import random
+
+import pytest
+
+from conftest import ROOT
+
+P = 0xFFFFFFFF00000001
+R = 1 << 64
+RINV = pow(R, -1, P)
+EDGE = [0, 1, 2, 0xFFFFFFFF, 0x100000000, 0x100000001, P - 1, P - 2, P - 0xFFFFFFFF, 0xFFFFFFFF00000000, 0xFFFFFFFE00000001,
+        0x8000000000000000, 0x7FFFFFFFFFFFFFFF, 0x00000001FFFFFFFF, 0xFFFFFFFEFFFFFFFF]
+ANY = EDGE + [P, P + 1, (1 << 64) - 1, (1 << 64) - 2, 0xFFFFFFFF00000002]  # non-canonical 64-bit representatives
+
+
+@pytest.fixture(scope="module")
+def gen():
+    spec = importlib.util.spec_from_file_location("gen_gl_asm", os.path.join(ROOT, "tools", "gen_gl_asm.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _env64(vbase, vals):
+    """vals: per butterfly slot b a dict name -> 64-bit value for x, y, t"""
+    env = {"%[pp]": P}
+    for b, v in enumerate(vals):
+        for nm, val in v.items():
+            env["%%[%s0_%d]" % (nm, b)] = val & 0xFFFFFFFF
+            env["%%[%s1_%d]" % (nm, b)] = val >> 32
+        env["v%d" % (vbase + 12 * b + 5)] = 0  # the pinned zero half
+    return env
+
+
+def _get(env, nm, b):
+    return env["%%[%s0_%d]" % (nm, b)] | (env["%%[%s1_%d]" % (nm, b)] << 32)
+
+
+def _cases(rng, pool_x, pool_y, n_random):
+    for x in pool_x:
+        for y in pool_y:
+            yield x, y
+    for _ in range(n_random):
+        yield rng.getrandbits(64), rng.getrandbits(64)
+
+
+@pytest.mark.parametrize("vbase", [104, 72, 56])
+def test_goldilocks_streams(gen, vbase):
+    rng = random.Random(vbase)
+    tw = EDGE + [rng.randrange(P) for _ in range(6)]
+    for kind in ("fwd", "inv", "mul"):
+        lines = gen.stream(kind, 2, vbase)
+        canon_in = kind == "fwd"  # forward butterflies take canonical words; the others any 64-bit representative of x
+        pool_x = EDGE if canon_in else ANY
+        n = 0
+        for x, y in _cases(rng, pool_x, EDGE, 300):
+            if canon_in:
+                x, y = x % P, y % P
+            else:
+                y = y % P  # inverse: y is a canonical transform-domain word; mul: unused
+            for t in (tw if n % 7 == 0 else tw[n % len(tw):][:2]):
+                vals = [{"x": x, "y": y, "t": t}, {"x": y if canon_in else x ^ 1, "y": x % P, "t": tw[(n + 3) % len(tw)]}]
+                if kind == "mul":
+                    vals = [{"x": v["x"], "t": v["t"]} for v in vals]
+                env = gen.simulate(lines, _env64(vbase, vals))
+                for b, v in enumerate(vals):
+                    gx = _get(env, "x", b)
+                    if kind == "fwd":
+                        assert gx == (v["x"] + v["y"]) % P, (kind, v)
+                        assert _get(env, "y", b) == (v["x"] - v["y"]) * v["t"] * RINV % P, (kind, v)
+                    elif kind == "inv":
+                        w = v["y"] * v["t"] * RINV % P
+                        assert gx < (1 << 64) and gx % P == (v["x"] + w) % P, (kind, v)
+                        assert _get(env, "y", b) % P == (v["x"] - w) % P, (kind, v)
+                    else:
+                        assert gx == v["x"] * v["t"] * RINV % P, (kind, v)  # canonical for ANY 64-bit multiplicand
+            n += 1
+
+
+@pytest.mark.parametrize("mode,p", [("lazy", 3329), ("lazy", 998244353), ("lazy", (1 << 30) - 35), ("small", (1 << 30) + 3),
+                                    ("small", (1 << 31) - 1), ("any", (1 << 31) + 11), ("any", 3221225473), ("any", (1 << 32) - 5),
+                                    ("any", 3), ("small", 5), ("lazy", 7)])
+def test_four_byte_word_streams(gen, mode, p):
+    rng = random.Random(p)
+    pinv = pow(p, -1, 1 << 32)
+    rinv = pow(1 << 32, -1, p)
+    top = 2 * p if mode == "lazy" else p  # lazy streams keep values in [0, 2p)
+    edge = sorted({0, 1, p - 1, p // 2, top - 1, top - 2 if top > 2 else 0, p % top, (p + 1) % top})
+    tws = sorted({0, 1, p - 1, p // 2 + 1}) + [rng.randrange(p) for _ in range(4)]
+    for kind in ("fwd32", "inv32"):
+        lines = gen.stream(kind, 4, mode=mode)
+        cases = [(x, y) for x in edge for y in edge] + [(rng.randrange(top), rng.randrange(top)) for _ in range(300)]
+        for i, (x, y) in enumerate(cases):
+            env = {"%[p]": p, "%[pinv]": pinv, "%[p2]": (2 * p) & 0xFFFFFFFF}
+            vals = []
+            for b in range(4):
+                xv, yv = (x, y) if b % 2 == 0 else (y, x)
+                t = tws[(i + b) % len(tws)]
+                vals.append((xv, yv, t))
+                env["%%[x_%d]" % b], env["%%[y_%d]" % b], env["%%[t_%d]" % b] = xv, yv, t
+            gen.simulate(lines, env)
+            for b, (xv, yv, t) in enumerate(vals):
+                gx, gy = env["%%[x_%d]" % b], env["%%[y_%d]" % b]
+                if kind == "fwd32":
+                    wx, wy = (xv + yv) % p, (xv - yv) * t * rinv % p
+                else:
+                    w = yv * t * rinv % p
+                    wx, wy = (xv + w) % p, (xv - w) % p
+                if mode == "lazy":
+                    assert gx < 2 * p and gy < 2 * p and gx % p == wx and gy % p == wy, (kind, mode, p, xv, yv, t)
+                else:
+                    assert (gx, gy) == (wx, wy), (kind, mode, p, xv, yv, t)

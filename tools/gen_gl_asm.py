@@ -5,11 +5,11 @@ Goldilocks butterflies (two independent butterflies interleaved per asm statemen
 Why asm: on gfx950 a VALU instruction that reads an SGPR/VCC written by a VALU instruction
 needs two other instructions in between (the compiler pads with s_nop), and hipcc turns the
 64-bit compare/select idiom into v_cmp_lt_u64 + 2x v_cndmask instead of carry chains.  One
-butterfly is 24 VALU instructions when written with v_add_co/v_addc_co/v_subb_co chains:
+butterfly is 22 VALU instructions when written with v_add_co/v_addc_co/v_subb_co chains:
 
   sub   d = x - y (mod p)                    4 VALU + 1 SALU
-  mul   r = d * T  (T in Montgomery form)    4 v_mad_u64_u32 + 10 VALU + 1 SALU (9: the zero half of one addend is a pinned register)
-  add   s = x + y (mod p)                    6 VALU + 1 SALU
+  mul   r = d * T  (T in Montgomery form)    4 v_mad_u64_u32 + 9 VALU + 2 SALU (zero half of one addend pinned; merged reduction)
+  add   s = x + y (mod p)                    5 VALU + 2 SALU
 
 The two butterflies' instructions are merged by a list scheduler that keeps every
 SGPR producer->consumer pair at least 3 slots apart, so no s_nop is needed.
@@ -17,7 +17,7 @@ SGPR producer->consumer pair at least 3 slots apart, so no s_nop is needed.
 Register use inside a statement: data words and 32-bit temporaries are compiler-allocated
 operands; the 64-bit products need aligned VGPR pairs whose halves are used separately, which
 inline-asm operands cannot express, so they live in fixed VGPRs v[108:127] (clobbers), and the
-carries in fixed SGPR pairs s[84:99] + vcc.  The s_or_b64 / s_andn2_b64 in the streams write
+carries in fixed SGPR pairs s[80:99].  The s_or_b64 / s_andn2_b64 in the streams write
 SCC, so SCC is declared clobbered too (without it hipcc scheduled an s_add_u32 / s_addc_u32 pair
 across a statement and the carry was lost).
 """
@@ -44,8 +44,8 @@ def butterfly(kind, b, vbase=104):
     d0 d1 (operands), fixed pairs L M A B H Z, SGPR pairs sa sb se sf."""
     vb = vbase + 12 * b
     L, M, A, B, H, Z = [(f"v{vb + 2 * i}", f"v{vb + 2 * i + 1}") for i in range(6)]
-    sb_ = 84 + 8 * b
-    sa, sbb, se, sf = [f"s[{sb_ + 2 * i}:{sb_ + 2 * i + 1}]" for i in range(4)]
+    sb_ = 80 + 10 * b
+    sa, sbb, se, sf, s5 = [f"s[{sb_ + 2 * i}:{sb_ + 2 * i + 1}]" for i in range(5)]  # s5: the product's sign while its fix-up is computed
 
     def P(pair):
         lo = int(pair[0][1:])
@@ -88,25 +88,29 @@ def butterfly(kind, b, vbase=104):
         ins.append(Ins(f"v_addc_co_u32 {a1}, {sf}, {a1}, 0, {se}", [a1, se], [a1, sf]))
 
     def mul(m0, m1, r0, r1):
-        # (m1:m0) * (t1:t0) * 2^-64 mod p, canonical; m may be any 64-bit value
-        ins.append(Ins(f"v_mad_u64_u32 {P(L)}, vcc, {m0}, {t0}, 0", [m0, t0], [L[0], L[1], "vcc"]))
+        # (m1:m0) * (t1:t0) * 2^-64 mod p, canonical; m may be any 64-bit value.
+        # Product P = (P3:P2:P1:P0) by four v_mad_u64_u32 (the carry-outs that mean nothing go to sbb), H = (P3:P2).
+        ins.append(Ins(f"v_mad_u64_u32 {P(L)}, {sbb}, {m0}, {t0}, 0", [m0, t0], [L[0], L[1], sbb]))
         ins.append(Ins(f"v_mov_b32 {A[0]}, {L[1]}", [L[1]], [A[0]]))
         # A[1] holds zero for the whole kernel: a register-pinned variable handed to the statement as an INPUT (emit()),
         # so the compiler materialises it once outside the batch loop instead of one v_mov per butterfly
-        ins.append(Ins(f"v_mad_u64_u32 {P(M)}, vcc, {m0}, {t1}, {P(A)}", [m0, t1, A[0], A[1]], [M[0], M[1], "vcc"]))
+        ins.append(Ins(f"v_mad_u64_u32 {P(M)}, {sbb}, {m0}, {t1}, {P(A)}", [m0, t1, A[0], A[1]], [M[0], M[1], sbb]))
         ins.append(Ins(f"v_mad_u64_u32 {P(M)}, {sa}, {m1}, {t0}, {P(M)}", [m1, t0, M[0], M[1]], [M[0], M[1], sa]))
         ins.append(Ins(f"v_mov_b32 {B[0]}, {M[1]}", [M[1]], [B[0]]))
         ins.append(Ins(f"v_cndmask_b32 {B[1]}, 0, 1, {sa}", [sa], [B[1]]))
-        ins.append(Ins(f"v_mad_u64_u32 {P(H)}, vcc, {m1}, {t1}, {P(B)}", [m1, t1, B[0], B[1]], [H[0], H[1], "vcc"]))
-        # Montgomery: a1 = P1 + P0 (carry e); b = (a1:P0) - a1 - e; r = H - b (mod p)
-        ins.append(Ins(f"v_add_co_u32 {A[0]}, {sa}, {M[0]}, {L[0]}", [M[0], L[0]], [A[0], sa]))
-        ins.append(Ins(f"v_subb_co_u32 {B[0]}, {sbb}, {L[0]}, {A[0]}, {sa}", [L[0], A[0], sa], [B[0], sbb]))
-        ins.append(Ins(f"v_subbrev_co_u32 {B[1]}, {sbb}, 0, {A[0]}, {sbb}", [A[0], sbb], [B[1], sbb]))
-        ins.append(Ins(f"v_sub_co_u32 {L[0]}, {sa}, {H[0]}, {B[0]}", [H[0], B[0]], [L[0], sa]))
-        ins.append(Ins(f"v_subb_co_u32 {L[1]}, {sa}, {H[1]}, {B[1]}, {sa}", [H[1], B[1], sa], [L[1], sa]))
-        ins.append(Ins(f"v_addc_co_u32 {r0}, {sbb}, {L[0]}, 0, {sa}", [L[0], sa], [r0, sbb]))
-        ins.append(Ins(f"s_andn2_b64 {sa}, {sa}, {sbb}", [sa, sbb], [sa], salu=True))
-        ins.append(Ins(f"v_subbrev_co_u32 {r1}, {sa}, 0, {L[1]}, {sa}", [L[1], sa], [r1, sa]))
+        ins.append(Ins(f"v_mad_u64_u32 {P(H)}, {sbb}, {m1}, {t1}, {P(B)}", [m1, t1, B[0], B[1]], [H[0], H[1], sbb]))
+        # Montgomery step for p = 2^64 - 2^32 + 1 (p^-1 = 2^32 + 1 mod 2^64): q = (a1:P0) with a1 = P1 + P0 (carry e), and
+        #   (P - q*p) / 2^64 = H - q + a1 + e = (H1 - a1 - e) * 2^32 + (H0 + P1 + e)        in (-p, p)
+        # (because a1 - P0 = P1 - e * 2^32): one add for a1, one add-with-carry per half, + p when negative.  6 VALU + 2 SALU
+        # (the q - a1 - e / H - b form it replaces was 7 + 1).
+        ins.append(Ins(f"v_add_co_u32 {A[0]}, {sa}, {M[0]}, {L[0]}", [M[0], L[0]], [A[0], sa]))                      # a1, e
+        ins.append(Ins(f"v_subb_co_u32 {L[1]}, {s5}, {H[1]}, {A[0]}, {sa}", [H[1], A[0], sa], [L[1], s5]))             # t = H1 - a1 - e, borrow
+        ins.append(Ins(f"v_addc_co_u32 {L[0]}, {sbb}, {H[0]}, {M[0]}, {sa}", [H[0], M[0], sa], [L[0], sbb]))           # lo = H0 + P1 + e, carry c
+        ins.append(Ins(f"v_addc_co_u32 {L[1]}, {sa}, {L[1]}, 0, {sbb}", [L[1], sbb], [L[1], sa]))                      # hi = t + c, carry g
+        ins.append(Ins(f"s_andn2_b64 {s5}, {s5}, {sa}", [s5, sa], [s5], salu=True))                                    # negative = borrow & ~g
+        ins.append(Ins(f"v_addc_co_u32 {r0}, {sbb}, {L[0]}, 0, {s5}", [L[0], s5], [r0, sbb]))                          # + p = - (2^32 - 1): lo + 1 ...
+        ins.append(Ins(f"s_andn2_b64 {s5}, {s5}, {sbb}", [s5, sbb], [s5], salu=True))
+        ins.append(Ins(f"v_subbrev_co_u32 {r1}, {s5}, 0, {L[1]}, {s5}", [L[1], s5], [r1, s5]))                         # ... hi - 1 unless lo carried
 
     if kind == "fwd":    # x' = x + y ; y' = (x - y) * T
         sub(d0, d1, x0, x1, y0, y1, d0, d1, d0, d1)
@@ -205,6 +209,91 @@ def butterfly32(kind, b, mode, vbase=None):
         add(x, tc, x)
     return ins
 
+
+
+# ---- one-lane interpreter of the generated streams (tests/test_gl_asm_sim.py checks them against big integers) ----------
+def simulate(lines, env):
+    """Execute the instruction texts on a dict of 32-bit registers / 1-bit flag pairs.  Operand spellings: %[name], vN,
+    v[a:b], s[a:b], vcc, integer literals.  Returns env."""
+    import re
+    M32 = 0xFFFFFFFF
+
+    def rd(op):
+        op = op.strip()
+        if re.fullmatch(r"-?\d+|0x[0-9a-fA-F]+", op):
+            return int(op, 0) & M32
+        return env[op]
+
+    def rd64(op):
+        op = op.strip()
+        if op == "0":
+            return 0
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", op)
+        if m:
+            return env["v" + m.group(1)] | (env["v" + m.group(2)] << 32)
+        return env[op]  # %[pp]: a 64-bit scalar
+
+    def wr64(op, v):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", op.strip())
+        env["v" + m.group(1)] = v & M32
+        env["v" + m.group(2)] = (v >> 32) & M32
+
+    for line in lines:
+        if line.startswith("s_nop"):
+            continue
+        op, rest = line.split(None, 1)
+        a = [x.strip() for x in rest.split(",")]
+        # re-join v[a:b] / s[a:b] operands (they contain no comma, nothing to do) -- operands are already whole
+        if op == "v_mov_b32":
+            env[a[0]] = rd(a[1])
+        elif op in ("v_add_co_u32", "v_addc_co_u32"):
+            cin = env[a[4]] if op == "v_addc_co_u32" else 0
+            t = rd(a[2]) + rd(a[3]) + cin
+            env[a[0]], env[a[1]] = t & M32, t >> 32
+        elif op in ("v_sub_co_u32", "v_subb_co_u32"):
+            cin = env[a[4]] if op == "v_subb_co_u32" else 0
+            t = rd(a[2]) - rd(a[3]) - cin
+            env[a[0]], env[a[1]] = t & M32, 1 if t < 0 else 0
+        elif op in ("v_subrev_co_u32", "v_subbrev_co_u32"):
+            cin = env[a[4]] if op == "v_subbrev_co_u32" else 0
+            t = rd(a[3]) - rd(a[2]) - cin
+            env[a[0]], env[a[1]] = t & M32, 1 if t < 0 else 0
+        elif op == "v_mad_u64_u32":
+            t = rd(a[2]) * rd(a[3]) + rd64(a[4])
+            wr64(a[0], t & ((1 << 64) - 1))
+            env[a[1]] = t >> 64
+        elif op == "v_cndmask_b32":
+            env[a[0]] = rd(a[2]) if env[a[3]] else rd(a[1])
+        elif op == "v_cmp_le_u64":
+            env[a[0]] = 1 if rd64(a[1]) <= rd64(a[2]) else 0
+        elif op == "s_or_b64":
+            env[a[0]] = env[a[1]] | env[a[2]]
+        elif op == "s_andn2_b64":
+            env[a[0]] = env[a[1]] & (1 - env[a[2]])
+        elif op == "s_orn2_b64":
+            env[a[0]] = env[a[1]] | (1 - env[a[2]])
+        elif op == "v_mul_lo_u32":
+            env[a[0]] = (rd(a[1]) * rd(a[2])) & M32
+        elif op == "v_mul_hi_u32":
+            env[a[0]] = (rd(a[1]) * rd(a[2])) >> 32
+        elif op == "v_add_u32":
+            env[a[0]] = (rd(a[1]) + rd(a[2])) & M32
+        elif op == "v_sub_u32":
+            env[a[0]] = (rd(a[1]) - rd(a[2])) & M32
+        elif op == "v_subrev_u32":
+            env[a[0]] = (rd(a[2]) - rd(a[1])) & M32
+        elif op == "v_min_u32":
+            env[a[0]] = min(rd(a[1]), rd(a[2]))
+        else:
+            raise ValueError("simulate: unknown instruction " + line)
+    return env
+
+
+def stream(kind, nb=2, vbase=104, mode=None):
+    """The scheduled instruction lines of one statement (what emit()/emit32() put into gl_asm.h)."""
+    if kind in ("fwd32", "inv32"):
+        return schedule([butterfly32(kind, b, mode, vbase if vbase != 104 else M32_VBASE) for b in range(nb)])
+    return schedule([butterfly(kind, b, vbase) for b in range(nb)])
 
 def emit32(kind, nb, mode, vbase=M32_VBASE):
     lists = [butterfly32(kind, b, mode, vbase) for b in range(nb)]
@@ -332,7 +421,7 @@ def emit(kind, nb, tw_constraint, vbase=104, suffix=""):
     if kind == "fwd":
         ins_ += ['[pp] "s"(0xFFFFFFFF00000001ull)']  # p, for the 64-bit compare of the modular add
     ins_ += [f'[zero_{b}] "v"(zero_{b})' for b in range(nb)]
-    clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 12 * nb) if r not in zero_regs] + [f'"s{r}"' for r in range(84, 84 + 8 * nb)]
+    clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 12 * nb) if r not in zero_regs] + [f'"s{r}"' for r in range(80, 80 + 10 * nb)]
     src.append("        : " + ", ".join(outs))
     src.append("        : " + ", ".join(ins_))
     src.append("        : " + ", ".join(clob) + ");")
