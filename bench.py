@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--batch", type=int, default=4096, help="polynomials per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-valu-floor", action="store_true",
+                    help="skip the VALU-floor leg (its launches carry the same kernel names: keep them out of a rocprofv3 --stats run)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the twiddle broadcast path")
     args = ap.parse_args()
@@ -281,7 +283,7 @@ def main():
         headline = logn == 16 and batch == 4096
         # measured here: what a plain copy of the same bytes achieves, and the VALU floor of the same kernels
         copy = device_copy_rate(torch, x, y, stream)
-        floor = valu_floor(torch, logn, p, batch, x, y, stream)
+        floor = None if args.no_valu_floor else valu_floor(torch, logn, p, batch, x, y, stream)
         # counters (rocprofv3 --pmc, separate runs of this command): quoted only when collected on these sources
         traffic, traffic_src = None, "counters are collected for the headline configuration only"
         valu_cnt, valu_src = None, traffic_src
@@ -314,7 +316,8 @@ def main():
             # the binding unit of this integer workload is the vector ALU: floor = the same kernels, loads from L2, no stores
             "valu_floor_pass_ms": floor,
             "valu_floor_frac_of_pass": ([f / float(v) for f, v in zip(floor, per_pass)] if floor else None),
-            "valu_floor_source": "measured in this run: libntt_hip_exp.so, NTT_DEBUG_FLAGS=3" if floor else "libntt_hip_exp.so absent",
+            "valu_floor_source": ("measured in this run: libntt_hip_exp.so, NTT_DEBUG_FLAGS=3" if floor else
+                                  "skipped (--no-valu-floor)" if args.no_valu_floor else "libntt_hip_exp.so absent"),
             "valu_counters": valu_cnt, "valu_counters_source": valu_src,
         }
         if world == 1 and not args.no_cpu_baseline:

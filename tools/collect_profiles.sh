@@ -12,8 +12,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
-BENCH5="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-valu-floor"
+BENCH5="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-valu-floor"
 cd /tmp
 python3 $ROOT/bench.py > "$SUM/${TAG}_bench.json"
 tail -c 600 "$SUM/${TAG}_bench.json"; echo
