@@ -17,7 +17,7 @@ def rand(batch, n, wb, p, seed):
         return (hi << 32) | lo
     return torch.randint(0, p, (batch, n), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)
 
-def timeit(fn, steps=10, warmup=2):
+def timeit(fn, steps=20, warmup=8):
     for _ in range(warmup): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps): fn()
