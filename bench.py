@@ -298,7 +298,11 @@ def main():
                             "what": "SQ_INSTS_VALU per butterfly, and SQ_INSTS_VALU x an ASSUMED 4 cycles / (1024 SIMDs x kernel "
                                     "cycles): an instruction-count estimate of VALU occupancy, not a busy-cycle measurement"}
         out["roofline"] = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "bound": "hbm",
+            "binding": "vector-ALU issue at the clock the 1400 W board power cap allows (2.0 of 2.4 GHz while this transform runs: "
+                       "profiles/r02_power_probe.txt, r02_sq_real_vs_floor.txt; DESIGN.md 3.4) -- HBM bytes and VALU instructions "
+                       "both cost joules, neither unit is saturated on its own",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "definition": "algorithmic bytes of one forward transform (2*N*8 B) x batch / summed duration of its "
                           "%d pass kernels (hipEvents on the launch stream); a %d-pass transform physically moves %dx its "

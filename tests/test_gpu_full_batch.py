@@ -155,3 +155,37 @@ def test_multi_iteration_batch_loops_u32(eng, oracle, p, g, logn, batch):
     assert np.array_equal(eng.to_host(f[rows]), oracle.ntt(eng.to_host(a[rows]), T, p, nthreads=4))
     assert pl.count_noncanonical(f) == 0
     assert torch.equal(pl.inverse(f), a)
+
+
+@pytest.mark.parametrize("logn,batch", [(13, 5), (16, 3), (21, 2)])
+def test_product_fused_middle_aliasing_and_three_pass(eng, oracle, logn, batch):
+    """The fused middle pass of the product (pass.h:run_product_pass) at odd batches, for a three-pass size (N = 2^21:
+    two inverse column passes, the fused middle, two forward column passes), and with the result buffer aliasing
+    either operand or neither -- all must give the oracle pipeline's words."""
+    import torch
+
+    p = GOLD
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, 8, 0)
+    T = pl.make_table(2, 7)
+    pl.set_twiddles(T)
+    rng = np.random.default_rng(logn)
+    a = (rng.integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p))
+    b = (rng.integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p))
+    a[0, :4] = [p - 1, 0, p - 1, 1]  # edge residues in the first unit
+    b[0, :4] = [p - 1, p - 1, 0, 2]
+    A, B = oracle.intt(a, T, p, nthreads=8), oracle.intt(b, T, p, nthreads=8)
+    want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p, nthreads=8)
+    da, db = eng.to_device(a, "cuda:0"), eng.to_device(b, "cuda:0")
+    c = pl.polymul_negacyclic(da, db)  # result aliases a
+    assert c.data_ptr() == da.data_ptr() and np.array_equal(eng.to_host(c), want)
+    assert pl.count_noncanonical(c) == 0
+    da, db = eng.to_device(a, "cuda:0"), eng.to_device(b, "cuda:0")
+    c = pl.polymul_negacyclic(da, db, db)  # result aliases b
+    assert np.array_equal(eng.to_host(c), want)
+    da, db = eng.to_device(a, "cuda:0"), eng.to_device(b, "cuda:0")
+    out = torch.zeros_like(da)
+    assert np.array_equal(eng.to_host(pl.polymul_negacyclic(da, db, out)), want)
+    # commutativity on the device: b * a gives the same words
+    da, db = eng.to_device(a, "cuda:0"), eng.to_device(b, "cuda:0")
+    assert np.array_equal(eng.to_host(pl.polymul_negacyclic(db, da)), want)
