@@ -58,21 +58,6 @@ void product_kernel(PassArgs<CI> aa, const typename CI::W *in_b, PassArgs<CF> af
     run_product_pass<CI, CF>(ex, aa, ab, af);
 }
 
-// which rounds keep their twiddles in registers across the batch loop (bit r), inverse and forward table each:
-// the innermost round has a different set per thread and stays resident; the outermost one of a one-unit workgroup
-// is wave-uniform and lives in SGPRs; the middle ones are re-read (L2) at the start of their round
-#ifndef NTT_PRODUCT_MASK
-#define NTT_PRODUCT_MASK(R, UNIFORM_TOP) ((UNIFORM_TOP) ? ((1 << ((R) -1)) | 1) : 1)
-#endif
-template <int LOG_M>
-struct ProductCfg {
-    static constexpr int LOG_NT = LOG_M >= 10 ? 9 : 8;
-    static constexpr int R = (LOG_M + 2) / 3;
-    static constexpr bool UNIFORM_TOP = LOG_NT + 3 - LOG_M == 0;  // one unit per workgroup: the top round's twiddles are SGPRs
-    using CI = PassCfg<FieldGL, LOG_M, 0, true, true, NTT_PRODUCT_MASK(R, UNIFORM_TOP), 3, LOG_NT, false>;
-    using CF = PassCfg<FieldGL, LOG_M, 0, true, false, NTT_PRODUCT_MASK(R, UNIFORM_TOP), 3, LOG_NT, false>;
-};
-
 template <int LOG_M>
 hipError_t launch_product(const ErasedArgs &e, hipStream_t s) {
     using CI = typename ProductCfg<LOG_M>::CI;

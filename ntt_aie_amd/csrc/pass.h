@@ -984,6 +984,22 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
     }
 }
 
+// The two configurations of the product's middle pass for one unit size (Goldilocks; pass_kernel-independent so that
+// the host index model instantiates exactly what kernels_gl_product.hip launches).  Which rounds keep their twiddles in
+// registers across the batch loop (bit r): the innermost round has a different set per thread and stays resident; the
+// outermost one of a one-unit workgroup is wave-uniform and lives in SGPRs; the others are read from the LDS table.
+#ifndef NTT_PRODUCT_MASK
+#define NTT_PRODUCT_MASK(R, UNIFORM_TOP) ((UNIFORM_TOP) ? ((1 << ((R) -1)) | 1) : 1)
+#endif
+template <int LOG_M>
+struct ProductCfg {
+    static constexpr int LOG_NT = LOG_M >= 10 ? 9 : 8;
+    static constexpr int R = (LOG_M + 2) / 3;
+    static constexpr bool UNIFORM_TOP = LOG_NT + 3 - LOG_M == 0;  // one unit per workgroup
+    using CI = PassCfg<FieldGL, LOG_M, 0, true, true, NTT_PRODUCT_MASK(R, UNIFORM_TOP), 3, LOG_NT, false>;
+    using CF = PassCfg<FieldGL, LOG_M, 0, true, false, NTT_PRODUCT_MASK(R, UNIFORM_TOP), 3, LOG_NT, false>;
+};
+
 // ---- launch geometry shared by host planner and host model ---------------------
 struct PassGeom {
     int log_ul, log_uh, log_up;

@@ -45,6 +45,82 @@ struct EmuExec {
     typename Cfg::W *lds() { return tile.data(); }
 };
 
+// host twin of GpuProductExec (kernels_gl_product.hip): all contexts of the workgroup stepped phase by phase
+template <class CI, class CF>
+struct EmuProductExec {
+    using W = typename CI::W;
+    std::vector<Ctx<CI>> ci;
+    std::vector<Ctx<CF>> cf;
+    std::vector<W> keep, pre, tile, tab_i, tab_f;
+    uint32_t bx, by;
+    int only_wave = -1;
+    EmuProductExec()
+        : ci(CI::NT), cf(CI::NT), keep((size_t) CI::NT * CI::E), pre((size_t) CI::NT * CI::E), tile(CI::LDS_WORDS),
+          tab_i(tw_table_words<CI>()), tab_f(tw_table_words<CF>()) {}
+    void init(const PassArgs<CI> &aa, const PassArgs<CF> &af) {
+        for (int t = 0; t < CI::NT; t++) {
+            phase_init<CI>(ci[t], aa, (uint32_t) t, bx, by);
+            phase_init<CF>(cf[t], af, (uint32_t) t, bx, by);
+        }
+    }
+    int lo() const { return only_wave < 0 ? 0 : 64 * only_wave; }
+    int hi() const { return only_wave < 0 ? CI::NT : 64 * only_wave + 64; }
+    template <class Fn>
+    void eachI(Fn &&f) { for (int t = lo(); t < hi(); t++) f(ci[t]); }
+    template <class Fn>
+    void eachF(Fn &&f) { for (int t = lo(); t < hi(); t++) f(cf[t]); }
+    template <class Fn>
+    void eachIF(Fn &&f) { for (int t = lo(); t < hi(); t++) f(ci[t], cf[t], &keep[(size_t) t * CI::E], &pre[(size_t) t * CI::E]); }
+    template <class B>
+    void sync(B) {}
+    uint32_t pg_base() const { return ci[0].pg_base; }
+    W *lds() { return tile.data(); }
+    W *tabI() { return tab_i.data(); }
+    W *tabF() { return tab_f.data(); }
+};
+
+template <int LOG_M>
+int run_product_mid(int n, uint32_t batch, uint32_t target_wgs, const uint64_t *a_in, const uint64_t *b_in, uint64_t *out,
+                    const uint64_t *tw_inv, const uint64_t *tw_fwd, uint64_t pw_scale) {
+    using CI = typename ProductCfg<LOG_M>::CI;
+    using CF = typename ProductCfg<LOG_M>::CF;
+    PassGeom g = pass_geometry(n, 0, LOG_M, 0, CI::LOG_U, true, batch, target_wgs);
+    PassArgs<CI> aa;
+    memset((void *) &aa, 0, sizeof(aa));
+    aa.in = a_in;
+    aa.tw = tw_inv;
+    aa.n = n;
+    aa.batch = batch;
+    aa.ppw = g.ppw;
+    aa.log_ul = g.log_ul;
+    aa.log_uh = g.log_uh;
+    aa.log_up = g.log_up;
+    aa.pg_stride = 1;
+    PassArgs<CI> ab = aa;
+    ab.in = b_in;
+    PassArgs<CF> af;
+    memset((void *) &af, 0, sizeof(af));
+    af.out = out;
+    af.tw = tw_fwd;
+    af.n = n;
+    af.batch = batch;
+    af.ppw = g.ppw;
+    af.log_ul = g.log_ul;
+    af.log_uh = g.log_uh;
+    af.log_up = g.log_up;
+    af.pg_stride = 1;
+    af.pw_scale = pw_scale;
+    EmuProductExec<CI, CF> ex;
+    for (uint32_t by = 0; by < g.grid_y; by++)
+        for (uint32_t bx = 0; bx < g.grid_x; bx++) {
+            ex.bx = bx;
+            ex.by = by;
+            memset(ex.tile.data(), 0xA5, ex.tile.size() * sizeof(uint64_t));
+            run_product_pass<CI, CF>(ex, aa, ab, af);
+        }
+    return 0;
+}
+
 struct Erased {
     const void *in;
     void *out;
@@ -264,6 +340,56 @@ int emu_forward_product(int word_bytes, int logn, uint64_t p, const void *T_plai
                                        : dispatch<FieldM32, false>(passes[i].contig, passes[i].log_m, e);
         if (rc) return rc;
         cur = out;
+    }
+    return 0;
+}
+
+// The negacyclic product c = Fwd(InvU(a) . InvU(b) . N^-1) the way ntt_polymul_negacyclic runs it for multi-pass Goldilocks
+// sizes: inverse column passes of both operands, the fused middle pass (pass.h: run_product_pass), forward column passes.
+// T_plain is the kind-2 table; a and b are overwritten (scratch), like on the device.
+int emu_polymul_fused(int logn, const void *T_plain, void *a, void *b, void *out, uint32_t batch, uint32_t target_wgs) {
+    const uint64_t p = GOLDILOCKS;
+    const size_t N = (size_t) 1 << logn;
+    std::vector<uint64_t> T(N), Ti, tf(N), ti(N);
+    for (size_t i = 0; i < N; i++) T[i] = ((const uint64_t *) T_plain)[i];
+    if (!invert_table(T, p, Ti)) return -5;
+    for (size_t i = 0; i < N; i++) {
+        tf[i] = to_table_form(T[i], p, 8);
+        ti[i] = to_table_form(Ti[i], p, 8);
+    }
+    const std::vector<PassDesc> passes = plan_passes(logn, 8);
+    if (passes.size() < 2 || contig_log_e(passes[0].log_m, 8, false) != 3) return -1;
+    Erased e;
+    memset(&e, 0, sizeof(e));
+    e.n = logn;
+    e.batch = batch;
+    e.target_wgs = target_wgs;
+    for (size_t i = passes.size(); i-- > 1;)
+        for (void *buf : {a, b}) {
+            e.in = buf;
+            e.out = buf;
+            e.tw = ti.data();
+            e.s0 = passes[i].s0;
+            const int rc = dispatch<FieldGL, true>(passes[i].contig, passes[i].log_m, e);
+            if (rc) return rc;
+        }
+    const uint64_t ninv = powmod((p + 1) / 2, (uint64_t) logn, p);
+    const uint64_t pw = to_table_form(to_table_form(ninv, p, 8), p, 8);
+    int rc = -1;
+    switch (passes[0].log_m) {
+#define PM(M) case M: rc = run_product_mid<M>(logn, batch, target_wgs, (const uint64_t *) a, (const uint64_t *) b, (uint64_t *) out, ti.data(), tf.data(), pw); break;
+        PM(7) PM(8) PM(9) PM(10) PM(11) PM(12)
+#undef PM
+        default: return -1;
+    }
+    if (rc) return rc;
+    for (size_t i = 1; i < passes.size(); i++) {
+        e.in = out;
+        e.out = out;
+        e.tw = tf.data();
+        e.s0 = passes[i].s0;
+        rc = dispatch<FieldGL, false>(passes[i].contig, passes[i].log_m, e);
+        if (rc) return rc;
     }
     return 0;
 }

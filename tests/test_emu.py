@@ -122,6 +122,33 @@ def test_fused_pointwise_first_pass(oracle):
             assert np.array_equal(out, oracle.ntt(oracle.pointwise(a, b, p, scale), T, p)), (wb, logn)
 
 
+@pytest.mark.parametrize("logn", [13, 14, 16, 17, 18, 19, 20])  # fused middle of 7, 8, 8, 9, 10, 11, 12 stages
+def test_product_fused_middle_pass(oracle, logn):
+    """The negacyclic product the way the device runs it for multi-pass Goldilocks sizes (pass.h: run_product_pass: last
+    inverse pass of both operands + pointwise + first forward pass per workgroup-resident unit, LDS twiddle tables,
+    register prefetch of operand b), in the host index model, against the oracle pipeline.  target_wgs 8 makes the
+    workgroups stream several polynomials (the batch loop and its prefetch hand-over)."""
+    p = GOLD
+    n = 1 << logn
+    batch = 3 if logn <= 17 else 2
+    T = oracle.make_table(2, n, p, 7)
+    rng = np.random.default_rng(logn)
+    a = rng.integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p)
+    b = rng.integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p)
+    a[0, :3] = [p - 1, 0, 1]
+    b[0, :3] = [p - 1, p - 1, 0]
+    A, B = oracle.intt(a, T, p, nthreads=4), oracle.intt(b, T, p, nthreads=4)
+    want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p, nthreads=4)
+    sa, sb, out = a.copy(), b.copy(), np.zeros_like(a)
+    rc = emu_lib.lib().emu_polymul_fused(logn, T.ctypes.data, sa.ctypes.data, sb.ctypes.data, out.ctypes.data, batch, 8)
+    assert rc == 0
+    assert np.array_equal(out, want), logn
+    # in place into the first operand, as the Python host does by default
+    sa, sb = a.copy(), b.copy()
+    assert emu_lib.lib().emu_polymul_fused(logn, T.ctypes.data, sa.ctypes.data, sb.ctypes.data, sa.ctypes.data, batch, 8) == 0
+    assert np.array_equal(sa, want), logn
+
+
 def test_composite_odd_modulus(oracle):
     """The reference never checks that p is prime and the 4-byte-word engine takes any odd modulus: the
     forward network is the same words as the oracle's `%` arithmetic, and the inverse exists whenever every
