@@ -2,10 +2,10 @@
 """Same-process, interleaved A/B of library builds (methodology: N variants x M rounds in ONE process, one device):
 per-pass kernel times of the forward transform from ntt_forward_profile (hipEvents around every pass).
 
-usage: ab_pass.py [--logn 16] [--batch 4096] [--rounds 7] [--reps 5] [--dbg FLAGS] [--inverse] NAME=path[,ENV=VAL...] ...
+usage: ab_pass.py [--logn 16] [--batch 4096] [--rounds 7] [--reps 5] [--dbg FLAGS] [--inverse] NAME=path[+ENV=VAL...] ...
   e.g. ab_pass.py base=ab/libntt_base.so new=ntt_aie_amd/libntt_hip.so
        ab_pass.py --dbg 3 exp=ntt_aie_amd/libntt_hip_exp.so     (VALU floor; experiment builds only)
-ENV=VAL pairs are set while that variant's plan is created (experiment builds read their knobs there).
++ENV=VAL pairs (e.g. +NTT_PLAN_SPLIT=9,7) are set while that variant's plan is created (experiment builds read their knobs there).
 Prints, per variant: median and min of the per-pass times and of their sum over all rounds."""
 import argparse
 import ctypes as C
@@ -37,7 +37,7 @@ stream = torch.cuda.current_stream()
 plans = []
 for v in args.variants:
     name, rest = v.split("=", 1)
-    parts = rest.split(",")
+    parts = rest.split("+")
     path = parts[0] if os.path.isabs(parts[0]) else os.path.join(ROOT, parts[0])
     env = dict(p.split("=", 1) for p in parts[1:])
     if args.dbg is not None:

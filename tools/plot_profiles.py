@@ -4,7 +4,7 @@ efficiency = 5.5*N*log2(N) operations / kernel time / peak, for the MI355X serie
 reference's recorded AIE and A100 series (their published numbers, copied below as data), and launch-to-completion time
 of the reference's 10-launch procedure beside the AIE's 16-tile series.
 
-usage: plot_profiles.py [profiles_dir]   -> profiles/efficiency_mi355x.png, profiles/exectime_mi355x.png, profiles/efficiency_mi355x.csv"""
+usage: plot_profiles.py [profiles_dir]   -> profiles/efficiency_mi355x.{png,csv}, profiles/kerneltime_mi355x.png, profiles/exectime_mi355x.png"""
 import os
 import sys
 
@@ -39,10 +39,14 @@ def main():
     prof = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles")
     mi1 = read_rows(os.path.join(prof, "kerneltime", "mi355x.csv"))
     mib = read_rows(os.path.join(prof, "kerneltime", "mi355x_batch.csv"))
+    rp = os.path.join(prof, "kerneltime", "mi355x_rocprof.csv")  # true kernel durations (rocprofv3), when collected
+    mir = read_rows(rp) if os.path.exists(rp) else {}
     series = {"Ryzen AI Engine (reference)": (AIE_KERNEL_US, PEAK_GOPS["aie"]),
               "NVIDIA A100 (reference)": (A100_KERNEL_US, PEAK_GOPS["a100"]),
-              "MI355X, batch 1": (mi1, PEAK_GOPS["mi355x"]),
+              "MI355X, batch 1 (hipEvents around the launch)": (mi1, PEAK_GOPS["mi355x"]),
               "MI355X, saturating batch (per transform)": (mib, PEAK_GOPS["mi355x"])}
+    if mir:
+        series["MI355X, batch 1 (rocprofv3 kernel time)"] = (mir, PEAK_GOPS["mi355x"])
     with open(os.path.join(prof, "efficiency_mi355x.csv"), "w") as f:
         f.write("series,N,kernel_us,gops,efficiency\n")
         for name, (rows, peak) in series.items():
@@ -72,6 +76,19 @@ def main():
     ax.grid(True)
     ax.legend()
     fig.savefig(os.path.join(prof, "efficiency_mi355x.png"), dpi=120, bbox_inches="tight")
+    # profile/plot_kerneltime.py: kernel microseconds against the data size
+    fig, ax = plt.subplots(figsize=(10, 6))
+    for name, (rows, _) in series.items():
+        if "saturating" in name:
+            continue
+        ns = sorted(rows)
+        ax.plot(ns, [rows[n] for n in ns], marker="o", label=name)
+    ax.set_xscale("log", base=2)
+    ax.set_xlabel("Data size")
+    ax.set_ylabel("Kernel Time (us)")
+    ax.grid(True)
+    ax.legend()
+    fig.savefig(os.path.join(prof, "kerneltime_mi355x.png"), dpi=120, bbox_inches="tight")
     fig, ax = plt.subplots(figsize=(10, 6))
     ax.plot(sorted(AIE16_EXEC_US), [AIE16_EXEC_US[n] for n in sorted(AIE16_EXEC_US)], marker="o", label="AIE, 16 tiles (reference)")
     if exe:
@@ -82,7 +99,7 @@ def main():
     ax.grid(True)
     ax.legend()
     fig.savefig(os.path.join(prof, "exectime_mi355x.png"), dpi=120, bbox_inches="tight")
-    print("wrote efficiency_mi355x.{csv,png}, exectime_mi355x.png under", prof)
+    print("wrote efficiency_mi355x.{csv,png}, kerneltime_mi355x.png, exectime_mi355x.png under", prof)
 
 
 if __name__ == "__main__":
