@@ -25,7 +25,10 @@
  *   - launches are asynchronous on the caller's hipStream_t (passed as void*;
  *     NULL = default stream).  A plan is immutable after ntt_plan_set_twiddles
  *     and may be shared by host threads; one plan per device.
- *   - no hidden allocation per call: the plan owns its device twiddle copies.
+ *   - no hidden allocation per call: the plan owns its device twiddle copies (and one counter word for
+ *     ntt_count_noncanonical, serialised by a mutex: the only entry point that writes plan state).
+ *   - the library reads no environment variable that can change a result (NTT_ROCTX=1 only adds ROCTX ranges);
+ *     experiment switches exist only in the separate libntt_hip_exp.so build that tools/ load.
  */
 #ifndef NTT_HIP_H
 #define NTT_HIP_H
@@ -136,10 +139,13 @@ int ntt_inverse(ntt_plan_t plan, const void *d_in, void *d_out, size_t batch,
 int ntt_pointwise_mul(ntt_plan_t plan, const void *d_a, const void *d_b, void *d_out,
                       size_t batch, uint64_t scale, void *stream);
 
-/* Negacyclic product c = a*b mod (x^N + 1, p) with a kind-2 table loaded:
- * unscaled inverse network on a and b -> forward network of a*b*N^-1, the pointwise
- * product being folded into the first pass's load.  d_a and d_b are overwritten (used as scratch);
- * d_out may alias d_a. */
+/* Negacyclic product c = a*b mod (x^N + 1, p) with a kind-2 table loaded (no reference counterpart; BASELINE config 4):
+ * c = Fwd( InvU(a) . InvU(b) . N^-1 ) with the unscaled inverse network InvU.  Multi-pass Goldilocks
+ * sizes (N >= 2^13) run the column passes of both inverse transforms, then ONE fused middle launch per unit of the
+ * first pass (last inverse pass of a and of b, word-by-word product, first forward pass: 3 N words of HBM traffic
+ * instead of 7 N), then the forward column passes; other sizes fold the product into the load of the forward
+ * transform's first pass.  d_a and d_b are overwritten (scratch); d_out may alias d_a or d_b.  When d_b directly follows
+ * d_a in memory (one [2*batch][N] buffer) both operand transforms run as one launch per pass. */
 int ntt_polymul_negacyclic(ntt_plan_t plan, void *d_a, void *d_b, void *d_out,
                            size_t batch, void *stream);
 

@@ -189,7 +189,7 @@ int run_inverse(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
 
 extern "C" {
 
-int ntt_version(void) { return 100; /* 0.1.0 */ }
+int ntt_version(void) { return 200; /* 0.2.0 */ }
 
 const char *ntt_error_string(int code) {
     switch (code) {
