@@ -96,7 +96,7 @@ def test_four_byte_word_streams(gen, mode, p):
         lines = gen.stream(kind, 4, mode=mode)
         cases = [(x, y) for x in edge for y in edge] + [(rng.randrange(top), rng.randrange(top)) for _ in range(300)]
         for i, (x, y) in enumerate(cases):
-            env = {"%[p]": p, "%[pinv]": pinv, "%[p2]": (2 * p) & 0xFFFFFFFF}
+            env = {"%[p]": p, "%[npinv]": (-pinv) & 0xFFFFFFFF, "%[p2]": (2 * p) & 0xFFFFFFFF}
             vals = []
             for b in range(4):
                 xv, yv = (x, y) if b % 2 == 0 else (y, x)

@@ -128,11 +128,12 @@ def butterfly(kind, b, vbase=104):
 def butterfly32(kind, b, mode, vbase=None):
     """4-byte-word Montgomery butterfly `b` (R = 2^32, twiddle in Montgomery form).
     mode "lazy":  p < 2^30, values kept in [0, 2p) (Harvey): no correction after the product, one
-                  v_min_u32 per sum; 10 (forward) / 11 (inverse) instructions.  Callers canonicalise
-                  once at the end of the transform.
-    mode "small": p < 2^31, canonical values, conditional corrections by v_min_u32 (12 instructions);
-    mode "any":   any odd p < 2^32, carries in SGPR pairs.
-    Operands: x y t (compiler), temporaries a b c, scalars %[p] %[pinv] (%[p2] = 2p when lazy); the
+                  v_min_u32 per sum; 9 (forward, one of them a plain move) / 9 (inverse) instructions.  Callers
+                  canonicalise once at the end of the transform.
+    mode "small": p < 2^31, canonical values, conditional corrections by v_min_u32 (11 instructions);
+    mode "any":   any odd p < 2^32, carries in SGPR pairs (12 instructions).
+    The Montgomery step is a second multiply-add (m*T + u*p, u = lo(m*T) * (-p^-1)): 3 instructions for the lazy product.
+    Operands: x y t (compiler), temporaries a b c, scalars %[p] %[npinv] = -p^-1 mod 2^32 (%[p2] = 2p when lazy); the
     64-bit product lives in a fixed VGPR pair."""
     small = mode == "small"
     L = (f"v{vbase + 2 * b}", f"v{vbase + 2 * b + 1}")
@@ -143,7 +144,7 @@ def butterfly32(kind, b, mode, vbase=None):
         return f"%[{name}{b}]"
 
     x, y, t, ta, tb, tc = o("x_"), o("y_"), o("t_"), o("a_"), o("b_"), o("c_")
-    P, PI, P2 = "%[p]", "%[pinv]", "%[p2]"
+    P, NPI, P2 = "%[p]", "%[npinv]", "%[p2]"
     ins = []
 
     def add(u, v, out):  # out = (u + v) mod p ; clobbers ta, tb
@@ -167,11 +168,21 @@ def butterfly32(kind, b, mode, vbase=None):
             ins.append(Ins(f"v_add_u32 {tmp}, {P}, {out}", [out], [tmp]))
             ins.append(Ins(f"v_cndmask_b32 {out}, {out}, {tmp}, {sb}", [out, tmp, sb], [out]))
 
-    def mul(m, out, t1, t2):  # out = m * T * 2^-32 mod p ; clobbers t1, t2
+    def mul(m, out, t1, t2):  # out = m * T * 2^-32 mod p, canonical ; clobbers t1, t2
+        # Montgomery step as a second multiply-ADD: u = lo(m*T) * (-p^-1), then m*T + u*p has a zero low half and its
+        # high half (plus the carry-out when p >= 2^31) is the result in [0, 2p): one v_mad_u64_u32 instead of
+        # v_mul_hi_u32 + subtract + add.
         ins.append(Ins(f"v_mad_u64_u32 {LP}, vcc, {m}, {t}, 0", [m, t], [L[0], L[1], "vcc"]))
-        ins.append(Ins(f"v_mul_lo_u32 {t1}, {L[0]}, {PI}", [L[0]], [t1]))
-        ins.append(Ins(f"v_mul_hi_u32 {t1}, {t1}, {P}", [t1], [t1]))
-        sub(L[1], t1, out, t2)
+        ins.append(Ins(f"v_mul_lo_u32 {t1}, {L[0]}, {NPI}", [L[0]], [t1]))
+        if small:  # 2p < 2^32: no carry
+            ins.append(Ins(f"v_mad_u64_u32 {LP}, vcc, {t1}, {P}, {LP}", [t1, L[0], L[1]], [L[0], L[1], "vcc"]))
+            ins.append(Ins(f"v_subrev_u32 {t2}, {P}, {L[1]}", [L[1]], [t2]))
+            ins.append(Ins(f"v_min_u32 {out}, {L[1]}, {t2}", [L[1], t2], [out]))
+        else:
+            ins.append(Ins(f"v_mad_u64_u32 {LP}, {sa}, {t1}, {P}, {LP}", [t1, L[0], L[1]], [L[0], L[1], sa]))
+            ins.append(Ins(f"v_subrev_co_u32 {t2}, {sb}, {P}, {L[1]}", [L[1]], [t2, sb]))
+            ins.append(Ins(f"s_orn2_b64 {sa}, {sa}, {sb}", [sa, sb], [sa], salu=True))  # carry | !borrow: r >= p
+            ins.append(Ins(f"v_cndmask_b32 {out}, {L[1]}, {t2}, {sa}", [L[1], t2, sa], [out]))
 
     # ---- lazy forms: every value in [0, 2p), 4p < 2^32 ----
     def lazy_add(u, v, out):  # out = u + v reduced to [0, 2p) ; clobbers ta, tb
@@ -179,25 +190,24 @@ def butterfly32(kind, b, mode, vbase=None):
         ins.append(Ins(f"v_subrev_u32 {tb}, {P2}, {ta}", [ta], [tb]))         # wraps (huge) when ta < 2p
         ins.append(Ins(f"v_min_u32 {out}, {ta}, {tb}", [ta, tb], [out]))
 
-    def lazy_mul(m, out, t1):  # out = m * T * 2^-32 + p in (0, 2p), any m < 2^32 with m * p < 2^62 ; clobbers t1
+    def lazy_mul(m, t1):  # L[1] = m * T * 2^-32 in [0, 2p) for any m < 2^32 (m*T + u*p < 2^33 * p < 2^63) ; clobbers t1
         ins.append(Ins(f"v_mad_u64_u32 {LP}, vcc, {m}, {t}, 0", [m, t], [L[0], L[1], "vcc"]))
-        ins.append(Ins(f"v_mul_lo_u32 {t1}, {L[0]}, {PI}", [L[0]], [t1]))
-        ins.append(Ins(f"v_mul_hi_u32 {t1}, {t1}, {P}", [t1], [t1]))
-        ins.append(Ins(f"v_sub_u32 {out}, {L[1]}, {t1}", [L[1], t1], [out]))    # in (-p, p)
-        ins.append(Ins(f"v_add_u32 {out}, {P}, {out}", [out], [out]))           # in (0, 2p)
+        ins.append(Ins(f"v_mul_lo_u32 {t1}, {L[0]}, {NPI}", [L[0]], [t1]))
+        ins.append(Ins(f"v_mad_u64_u32 {LP}, vcc, {t1}, {P}, {LP}", [t1, L[0], L[1]], [L[0], L[1], "vcc"]))
 
     if mode == "lazy":
         if kind == "fwd32":    # x' = x + y ; y' = (x - y + 2p) * T
             ins.append(Ins(f"v_sub_u32 {tc}, {x}, {y}", [x, y], [tc]))
             ins.append(Ins(f"v_add_u32 {tc}, {P2}, {tc}", [tc], [tc]))          # in (0, 4p)
             lazy_add(x, y, x)
-            lazy_mul(tc, y, ta)
-        else:                  # w = y * T ; x' = x + w ; y' = x - w
-            lazy_mul(y, tc, ta)
-            ins.append(Ins(f"v_sub_u32 {y}, {x}, {tc}", [x, tc], [y]))          # wraps (huge) when x < w
+            lazy_mul(tc, ta)
+            ins.append(Ins(f"v_mov_b32 {y}, {L[1]}", [L[1]], [y]))
+        else:                  # w = y * T ; x' = x + w ; y' = x - w   (w stays in the product's high half)
+            lazy_mul(y, ta)
+            ins.append(Ins(f"v_sub_u32 {y}, {x}, {L[1]}", [x, L[1]], [y]))      # wraps (huge) when x < w
             ins.append(Ins(f"v_add_u32 {tb}, {P2}, {y}", [y], [tb]))            # then this one is x - w + 2p
             ins.append(Ins(f"v_min_u32 {y}, {y}, {tb}", [y, tb], [y]))
-            lazy_add(x, tc, x)
+            lazy_add(x, L[1], x)
         return ins
     if kind == "fwd32":    # x' = x + y ; y' = (x - y) * T
         sub(x, y, tc, ta)
@@ -315,7 +325,7 @@ def emit32(kind, nb, mode, vbase=M32_VBASE):
         outs += [f'[x_{b}] "+v"(x{b})', f'[y_{b}] "+v"(y{b})']
         outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("a_", "b_", "c_")]
         ins_ += [f'[t_{b}] "v"(t{b})']
-    ins_ += ['[p] "s"(p)', '[pinv] "s"(pinv)']
+    ins_ += ['[p] "s"(p)', '[npinv] "s"(0u - pinv)']
     if mode == "lazy":
         ins_ += ['[p2] "s"(p2)']
     clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 2 * nb)]
