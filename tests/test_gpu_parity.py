@@ -660,3 +660,46 @@ def test_goldilocks_inverse_lazy_representatives(eng, oracle):
             assert pl.count_noncanonical(un) == 0
             want = np.array([[(int(v) * n) % p for v in row] for row in a[:, :64]], dtype=np.uint64)
             assert np.array_equal(eng.to_host(un)[:, :64], want), logn
+
+
+def test_shared_plan_from_two_host_threads_and_streams(eng, oracle):
+    """include/ntt_hip.h: a plan is immutable after set_twiddles and may be shared by host threads.  Two threads drive the
+    same plan on their own streams (forward, inverse, count_noncanonical -- the one entry point that writes plan state, behind
+    a mutex) while the main thread checks every result against the oracle."""
+    import threading
+
+    import torch
+
+    p, logn, batch = GOLD, 14, 24
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, 8, 0)
+    T = pl.make_roots(7)
+    pl.set_twiddles(T)
+    data = [_rand(batch, n, p, np.uint64, 900 + i) for i in range(2)]
+    want = [oracle.ntt(a, T, p, nthreads=4) for a in data]
+    results, errors = [None, None], []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(0)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                x = eng.to_device(data[i], "cuda:0")
+                for _ in range(25):
+                    f = pl.forward(x, stream=s)
+                    back = pl.inverse(f, stream=s)
+                    s.synchronize()
+                    assert pl.count_noncanonical(f) == 0
+                    assert torch.equal(back, x)
+                results[i] = eng.to_host(f)
+        except Exception as e:  # surfaced in the main thread
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for i in range(2):
+        assert np.array_equal(results[i], want[i])
