@@ -245,6 +245,8 @@ def main():
     out = {
         "metric": "forward-NTT/s, N=2^%d 64-bit Goldilocks prime, batch=%d per GPU" % (logn, batch),
         "value": value, "unit": "NTT/s", "butterflies_per_s": value * (n // 2) * logn,
+        # the reference's own operation count (profile/plot_efficiency.py:25,44: 5.5 * N * log2 N per transform)
+        "ops_per_s_reference_convention": value * 5.5 * n * logn,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
