@@ -47,6 +47,10 @@
 #ifndef NTT_LATE_SYNC
 #define NTT_LATE_SYNC 0  // experiment knob: end-of-iteration barrier moved to before the next iteration's first LDS write (measured: column pass +2 %, worse)
 #endif
+#ifndef NTT_COL_DMA
+#define NTT_COL_DMA 0  // experiment knob: LDS-DMA prefetch in the 8-stage Goldilocks column pass, ONE tile buffer (the next
+                       // tile lands in it while the second round computes); measured in DESIGN.md section 8.5
+#endif
 #ifndef NTT_PRODUCT_PREFETCH_A
 #define NTT_PRODUCT_PREFETCH_A 0  // product pass: also prefetch the NEXT unit's operand a during the forward rounds (b is always prefetched)
 #endif
@@ -100,7 +104,7 @@ struct PassCfg {
     static constexpr int VW = 16 / (int) sizeof(W);        // words per 16-byte chunk
     static constexpr int TILE_WORDS = NT * E;
     // one 16-byte pad per E words keeps 16-byte alignment and skews the lanes
-    static constexpr int LDS_WORDS = TILE_WORDS + (TILE_WORDS >> LOG_E) * VW;  // (2 * TILE_WORDS when DMA)
+    static constexpr int LDS_WORDS_PADDED = TILE_WORDS + (TILE_WORDS >> LOG_E) * VW;  // (2 * TILE_WORDS when DMA)
 
     static constexpr int win(int r) { return r * LOG_E > LOG_M - LOG_E ? LOG_M - LOG_E : r * LOG_E; }
     static constexpr int stage_lo(int r) { return r * LOG_E; }
@@ -125,13 +129,23 @@ struct PassCfg {
     // ALLOW_DMA_ = false: the same radix-8 kernel with the tile staged by ordinary loads (phase_linear),
     // which is where a fused pointwise product has room to multiply.
     static constexpr bool DMA = ALLOW_DMA_ && CONTIG && !INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8;
+    // Column pass of 8 stages on 8-byte words (256 rows x one 128-byte segment, one unit per workgroup): the NEXT tile is
+    // fetched by LDS-DMA into the SAME buffer once the second round's words are in registers (experiment, NTT_COL_DMA).
+    // A wave-instruction lands 8 rows (1 KiB) linearly; 128 bytes of padding after every 16 rows keep the first round's
+    // reads (rows 16q + e of thread q) and the second round's (rows q + 16e) free of bank conflicts.
+    static constexpr bool CDMA = NTT_COL_DMA && ALLOW_DMA_ && !CONTIG && !INV && sizeof(W) == 8 && LOG_E_ == 4 && LOG_C_ == 4 &&
+                                 LOG_M_ == 8 && LOG_NT_ == 8;
     // column passes of 8-byte words: the NEXT polynomial's 16 words per thread are loaded into a second
     // register set while the current one is transformed (experiment knob NTT_COL_PREFETCH)
     // ... and the inverse CONTIG radix-8 passes (direct loads of 8 words per thread, no DMA): NTT_INV_PREFETCH
     static constexpr bool REG_PREFETCH = (NTT_COL_PREFETCH && !CONTIG && sizeof(W) == 8 && LOG_M_ == 8) ||
                                          (NTT_INV_PREFETCH && CONTIG && INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8);
 
-    static NTT_HD uint32_t lds_index(uint32_t lin) { return DMA ? lin : lin + ((lin >> LOG_E) * VW); }
+    static constexpr int LDS_WORDS = CDMA ? TILE_WORDS + (TILE_WORDS >> 8) * 16 : LDS_WORDS_PADDED;
+    static NTT_HD uint32_t lds_index(uint32_t lin) {
+        if (CDMA) return lin + ((lin >> 8) << 4);  // 16 words after every 16 rows of 16 words
+        return DMA ? lin : lin + ((lin >> LOG_E) * VW);
+    }
 };
 
 // Which rounds of a CONTIG pass keep their twiddles in registers across the batch loop.
@@ -236,6 +250,7 @@ struct Ctx {
 template <class Cfg>
 constexpr uint32_t lds_elem_off(int r, int e) {
     const uint32_t lin = (uint32_t) e << (Cfg::win(r) + Cfg::LOG_C);
+    if (Cfg::CDMA) return lin + ((lin >> 8) << 4);
     return Cfg::DMA ? lin : lin + ((lin >> Cfg::LOG_E) * Cfg::VW);
 }
 
@@ -446,7 +461,7 @@ NTT_HD void phase_store_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t voff = c.lane_st * (uint32_t) sizeof(W);
-    if constexpr (Cfg::DMA) {
+    if constexpr (Cfg::DMA || Cfg::CDMA) {
         // The LDS-DMA wait of the next iteration counts on EXACTLY E store instructions being
         // younger than the prefetch (phase_dma_wait): issue them by hand so that no compiler
         // decision (merging, splitting) can change that number.  Raw SRD: base, stride 0,
@@ -461,7 +476,7 @@ NTT_HD void phase_store_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
         asm volatile("s_nop 4" ::: "memory");  // v_readfirstlane -> VMEM descriptor read
 #pragma unroll
         for (int e = 0; e < Cfg::E; ++e) {
-            const uint32_t so = __builtin_amdgcn_readfirstlane(((uint32_t) e << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W));
+            const uint32_t so = __builtin_amdgcn_readfirstlane((elem_eff<Cfg>(a, e, !Cfg::INV) << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W));
             asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen nt" ::"v"(c.x[e]), "v"(voff), "s"(srd), "s"(so) : "memory");
         }
         return;
@@ -562,6 +577,27 @@ NTT_HD void phase_dma_issue(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W
         const uint32_t lin = wbase + (uint32_t) i * 64 * V + (c.tid & 63u) * V;
         for (int k = 0; k < V; ++k) lds[buf + lin + k] = a.in[tile0 + lin + k];
     }
+#endif
+}
+
+// Column tile (Cfg::CDMA): wave w fetches rows [64w, 64w + 64) of the 256-row tile, 8 rows (8 x 128 bytes) per instruction:
+// lane l copies the 16 bytes at row (l >> 3), piece (l & 7).  Device only (experiment knob).
+template <class Cfg>
+NTT_HD void phase_dma_issue_col(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *lds, int it) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using W = typename Cfg::W;
+    const size_t tile0 = uniform_word<Cfg>(c, a, it);
+    const uint32_t wave = c.tid >> 6, lane = c.tid & 63u;
+    const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) W *) lds;
+    const W *g = a.in + tile0 + ((size_t) (wave * 64u + (lane >> 3)) << a.s0) + (lane & 7u) * 2u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint32_t chunk = wave * 8u + (uint32_t) i;  // 8 rows = 1 KiB each; 128 bytes of padding after every 2 chunks
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + chunk * 1024u + (chunk >> 1) * 128u);
+        glds16(g + ((size_t) (8 * i) << a.s0), dst);
+    }
+#else
+    (void) c; (void) a; (void) lds; (void) it;
 #endif
 }
 
@@ -766,6 +802,38 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     }
     if constexpr (Cfg::REG_PREFETCH) {
         if (group_valid(0)) ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, 0); phase_load_direct<Cfg, FIRST, true>(c, a, 0); });
+    }
+    if constexpr (Cfg::CDMA) {
+        // One tile buffer: [wait for this wave's pieces] barrier [read round 0] compute [write] barrier [read round 1]
+        // barrier [issue the NEXT tile's DMA into the same buffer] compute round 1, store.
+        static_assert(R == 2 && Cfg::LOG_U == 0 && !Cfg::INV, "8-stage forward column pass");
+        if (group_valid(0)) ex.each([&](C &c) { phase_dma_issue_col<Cfg>(c, a, ex.lds(), 0); });
+        for (int it = 0; it < a.ppw; ++it) {
+            if (!group_valid(it)) break;
+            ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, it); });
+            typename Cfg::W *const tile = ex.lds();
+#if defined(NTT_EXPERIMENT)
+            const bool no_stores = (a.dbg & 2) != 0;  // timing experiment: nothing younger than the DMA to leave in flight
+#else
+            const bool no_stores = false;
+#endif
+            if (it == 0 || no_stores) ex.each([&](C &) { phase_dma_wait<Cfg, true>(); });
+            else ex.each([&](C &) { phase_dma_wait<Cfg, false>(); });
+            ex.sync(std::false_type{});  // every wave's rows have landed
+            ex.each([&](C &c) { phase_lds_read<Cfg, 0>(c, tile); });
+            ex.each([&](C &c) { phase_compute<Cfg, 0, M32_MODE>(c, a); });
+            ex.each([&](C &c) { phase_lds_write<Cfg, 0>(c, tile); });
+            ex.sync(std::false_type{});
+            ex.each([&](C &c) { phase_lds_read<Cfg, 1>(c, tile); });
+            ex.sync(std::false_type{});  // the tile is dead: the next one may land in it
+            wave_prio(NTT_SETPRIO & 1);
+            if (group_valid(it + 1)) ex.each([&](C &c) { phase_dma_issue_col<Cfg>(c, a, ex.lds(), it + 1); });
+            wave_prio(0);
+            ex.each([&](C &c) { phase_compute<Cfg, 1, M32_MODE>(c, a); });
+            ex.each([&](C &c) { phase_canon<Cfg>(c, a); });
+            ex.each([&](C &c) { phase_store_direct<Cfg, 1>(c, a, it); });
+        }
+        return;
     }
     int completed = 0;
     for (int it = 0; it < a.ppw; ++it) {
