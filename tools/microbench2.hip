@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #define REP8(x) x x x x x x x x
 #define ITERS 2000
 
@@ -88,9 +90,30 @@ double run(K kern, uint32_t *d_out) {
     return (double) ms * 1e6 / ((double) ITERS * 64 * 8);  // ns per wave-instruction per SIMD
 }
 
-int main() {
+// power mode (tools/energy_probe.py samples rocm-smi meanwhile): loop ONE kernel for about `seconds`, print its time per
+// wave-instruction per SIMD.   microbench2 power <kernel name> <seconds>
+template <class K>
+void loop_for(K kern, uint32_t *d_out, double seconds, const char *name) {
+    double t = run(kern, d_out);  // ns per wave-instruction per SIMD, also the warm-up
+    const double launch_s = t * 1e-9 * ITERS * 64 * 8;
+    const int launches = (int) (seconds / launch_s) + 1;
+    for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(kern, dim3(512), dim3(1024), 0, 0, d_out, ITERS);
+    (void) hipDeviceSynchronize();
+    printf("%s %.4f ns per wave-instruction per SIMD, %d launches\n", name, t, launches);
+}
+
+int main(int argc, char **argv) {
     uint32_t *d_out;
     (void) hipMalloc(&d_out, 512 * 1024 * 4);
+    if (argc >= 4 && !strcmp(argv[1], "power")) {
+        const double sec = atof(argv[3]);
+#define P(K) if (!strcmp(argv[2], #K)) { loop_for(K, d_out, sec, #K); return 0; }
+        P(k_add_u32) P(k_mov_b32) P(k_and_b32) P(k_min_u32) P(k_mul_lo_u32) P(k_mul_hi_u32) P(k_add_co_sgpr) P(k_addc_vcc)
+        P(k_cndmask_sgpr) P(k_subbrev_sgpr) P(k_mad_u64_u32) P(k_mad_u64_u32_c0) P(k_lshl_add_u64) P(k_cmp_le_u64_sconst)
+        P(k_cmp_ne_u32_sgpr) P(k_fma_f32) P(k_pk_fma_f32) P(k_fma_f64) P(k_add_sgpr)
+        fprintf(stderr, "unknown kernel %s\n", argv[2]);
+        return 1;
+    }
     double base = run(k_add_u32, d_out);
     base = run(k_add_u32, d_out);
 #define R(K) { double t = run(K, d_out); printf("%-20s %.3f ns  x%.2f\n", #K, t, t / base); }
