@@ -545,10 +545,11 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
     const size_t operand_bytes = (batch << pl->logn) * (size_t) pl->word_bytes;
     const bool contiguous = (const char *) d_b == (const char *) d_a + operand_bytes && 2 * batch <= 0x7FFFFFFFull;
     const PassDesc &first = pl->passes.front();
-    const bool fused_mid = pl->word_bytes == 8 && pl->passes.size() >= 2 && first.contig &&
-                           ntt::contig_log_e(first.log_m, 8, false) == 3 && ntt::have_gl_product_mid(first.log_m);
+    // Goldilocks, first (or only) pass of 7..12 stages: the radix-8 product kernel exists for that unit size.  A single-pass
+    // size (2^7 <= N <= 2^12) is then ONE launch for the whole product: read a, read b, write c.
+    const bool fused_mid = pl->word_bytes == 8 && first.contig && ntt::have_gl_product_mid(first.log_m);
     if (fused_mid) {
-        // Multi-pass Goldilocks sizes: the column passes of both unscaled inverse transforms, then ONE launch that runs
+        // The column passes (if any) of both unscaled inverse transforms, then ONE launch that runs
         // the last inverse pass of a and of b, the pointwise product * N^-1 and the first forward pass on each
         // 2^log_m-word unit while it is workgroup-resident (3 N words of HBM traffic instead of 7 N), then the
         // forward column passes.

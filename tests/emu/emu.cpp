@@ -358,7 +358,7 @@ int emu_polymul_fused(int logn, const void *T_plain, void *a, void *b, void *out
         ti[i] = to_table_form(Ti[i], p, 8);
     }
     const std::vector<PassDesc> passes = plan_passes(logn, 8);
-    if (passes.size() < 2 || contig_log_e(passes[0].log_m, 8, false) != 3) return -1;
+    if (passes[0].log_m < 7 || passes[0].log_m > 12) return -1;  // unit sizes the product kernel exists for
     Erased e;
     memset(&e, 0, sizeof(e));
     e.n = logn;

@@ -122,7 +122,7 @@ def test_fused_pointwise_first_pass(oracle):
             assert np.array_equal(out, oracle.ntt(oracle.pointwise(a, b, p, scale), T, p)), (wb, logn)
 
 
-@pytest.mark.parametrize("logn", [13, 14, 16, 17, 18, 19, 20])  # fused middle of 7, 8, 8, 9, 10, 11, 12 stages
+@pytest.mark.parametrize("logn", [7, 9, 10, 12, 13, 14, 16, 17, 18, 19, 20])  # whole product in one pass (N <= 2^12); fused middle of 7 ... 12 stages
 def test_product_fused_middle_pass(oracle, logn):
     """The negacyclic product the way the device runs it for multi-pass Goldilocks sizes (pass.h: run_product_pass: last
     inverse pass of both operands + pointwise + first forward pass per workgroup-resident unit, LDS twiddle tables,
@@ -130,7 +130,7 @@ def test_product_fused_middle_pass(oracle, logn):
     workgroups stream several polynomials (the batch loop and its prefetch hand-over)."""
     p = GOLD
     n = 1 << logn
-    batch = 3 if logn <= 17 else 2
+    batch = 37 if logn <= 12 else (3 if logn <= 17 else 2)  # small N: several polynomials per workgroup, ragged tail
     T = oracle.make_table(2, n, p, 7)
     rng = np.random.default_rng(logn)
     a = rng.integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p)

@@ -189,3 +189,32 @@ def test_product_fused_middle_aliasing_and_three_pass(eng, oracle, logn, batch):
     # commutativity on the device: b * a gives the same words
     da, db = eng.to_device(a, "cuda:0"), eng.to_device(b, "cuda:0")
     assert np.array_equal(eng.to_host(pl.polymul_negacyclic(db, da)), want)
+
+
+@pytest.mark.parametrize("logn,batch", [(7, 100003), (10, 16411), (12, 8192)])
+def test_single_pass_product_one_launch(eng, oracle, logn, batch):
+    """Goldilocks, 2^7 <= N <= 2^12: the whole negacyclic product is ONE launch of the product kernel (inverse network on
+    a, on b, pointwise, forward network; several polynomials per workgroup below N = 2^11, ragged batch tail): sampled
+    rows against the oracle pipeline and against the schoolbook product, a * 1 = a over the whole batch."""
+    import torch
+
+    p = GOLD
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, 8, 0)
+    T = pl.make_table(2, 7)
+    pl.set_twiddles(T)
+    assert pl.hbm_passes == 1
+    a = _device_batch(torch, batch, n, p, 8, logn)
+    b = _device_batch(torch, batch, n, p, 8, logn + 50)
+    rows = [0, 1, 2, batch // 2, batch - 3, batch - 2, batch - 1]
+    ah, bh = eng.to_host(a[rows]), eng.to_host(b[rows])
+    A, B = oracle.intt(ah, T, p, nthreads=4), oracle.intt(bh, T, p, nthreads=4)
+    want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p, nthreads=4)
+    c = pl.polymul_negacyclic(a.clone(), b.clone())
+    assert np.array_equal(eng.to_host(c[rows]), want)
+    if logn <= 8:
+        assert np.array_equal(want[:3], np.stack([oracle.negacyclic_schoolbook(ah[i], bh[i], p) for i in range(3)]).astype(np.uint64))
+    assert pl.count_noncanonical(c) == 0
+    one = torch.zeros_like(b)
+    one[:, 0] = 1
+    assert torch.equal(pl.polymul_negacyclic(a.clone(), one), a)

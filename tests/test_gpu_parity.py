@@ -161,7 +161,7 @@ def test_error_paths(eng):
 def test_pointwise_and_negacyclic_polymul(eng, oracle):
     for wb, p, g in [(8, GOLD, 7), (4, 998244353, 3)]:
         dt = np.uint32 if wb == 4 else np.uint64
-        for logn in (2, 4, 6, 8, 13):
+        for logn in (2, 4, 6, 7, 8, 9, 11, 12, 13):  # Goldilocks 7..12: the whole product is ONE launch of the radix-8 product kernel
             n = 1 << logn
             pl = eng.NTTPlan(logn, p, wb, 0)
             T = pl.make_table(2, g)
