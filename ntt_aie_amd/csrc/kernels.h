@@ -37,7 +37,9 @@ hipError_t launch_m32_inv(bool contig, int log_m, const ErasedArgs &a, hipStream
 // and of a.in2, word-by-word product * pw_scale, forward CONTIG pass -> a.out.  tw = inverse table, tw2 = forward table.
 // hipErrorInvalidValue when this (word size, log_m) has no fused kernel (callers then run the separate passes).
 hipError_t launch_gl_product_mid(int log_m, const ErasedArgs &a, hipStream_t s);
-bool have_gl_product_mid(int log_m);
+bool have_gl_product_mid(int log_m);   // Goldilocks: unit sizes 2^7 .. 2^12
+hipError_t launch_m32_product_mid(int log_m, const ErasedArgs &a, hipStream_t s);
+bool have_m32_product_mid(int log_m);  // 4-byte words: unit sizes 2^5 .. 2^12
 
 #if defined(NTT_EXPERIMENT)
 // Tools-side experiment, NOT part of libntt_hip.so (tools/fused_gl16.hip, libntt_hip_exp.so only):

@@ -1,0 +1,23 @@
+// kernels_m32_product.hip -- the same fused middle pass for 4-byte words (any odd p < 2^32): radix-16 rounds, unit sizes
+// 2^5 .. 2^12; for N <= 2^12 the launch is the whole negacyclic product.
+#include "product_kernel.inc"
+
+namespace ntt {
+
+bool have_m32_product_mid(int log_m) { return log_m >= 5 && log_m <= 12; }
+
+hipError_t launch_m32_product_mid(int log_m, const ErasedArgs &a, hipStream_t s) {
+    switch (log_m) {
+        case 5: return launch_product<ProductCfgM32<5>>(a, s);
+        case 6: return launch_product<ProductCfgM32<6>>(a, s);
+        case 7: return launch_product<ProductCfgM32<7>>(a, s);
+        case 8: return launch_product<ProductCfgM32<8>>(a, s);
+        case 9: return launch_product<ProductCfgM32<9>>(a, s);
+        case 10: return launch_product<ProductCfgM32<10>>(a, s);
+        case 11: return launch_product<ProductCfgM32<11>>(a, s);
+        case 12: return launch_product<ProductCfgM32<12>>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace ntt

@@ -547,7 +547,9 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
     const PassDesc &first = pl->passes.front();
     // Goldilocks, first (or only) pass of 7..12 stages: the radix-8 product kernel exists for that unit size.  A single-pass
     // size (2^7 <= N <= 2^12) is then ONE launch for the whole product: read a, read b, write c.
-    const bool fused_mid = pl->word_bytes == 8 && first.contig && ntt::have_gl_product_mid(first.log_m);
+    // ... 4-byte words: radix-16 product kernel, unit sizes 2^5 .. 2^12 (any odd p: all three butterfly streams).
+    const bool fused_mid = first.contig && (pl->word_bytes == 8 ? ntt::have_gl_product_mid(first.log_m)
+                                                                 : ntt::have_m32_product_mid(first.log_m));
     if (fused_mid) {
         // The column passes (if any) of both unscaled inverse transforms, then ONE launch that runs
         // the last inverse pass of a and of b, the pointwise product * N^-1 and the first forward pass on each
@@ -561,7 +563,8 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
                 ntt::ErasedArgs a = base_args(pl, pd, buf, buf, contiguous ? 2 * batch : batch);
                 a.tw = pl->d_tw_inv;
                 a.layout = NTT_LAYOUT_NATURAL;
-                hipError_t e = ntt::launch_gl_inv(pd.contig, pd.log_m, a, s);
+                hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_inv(pd.contig, pd.log_m, a, s)
+                                                   : ntt::launch_m32_inv(pd.contig, pd.log_m, a, s);
                 if (e != hipSuccess) return (int) e;
             }
         }
@@ -572,8 +575,9 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
             a.tw = pl->d_tw_inv;
             a.tw2 = pl->d_tw_fwd;
             a.layout = NTT_LAYOUT_NATURAL;
-            a.pw_scale = to_table_form(to_table_form(pl->ninv_plain % pl->p, pl->p, 8), pl->p, 8);
-            hipError_t e = ntt::launch_gl_product_mid(first.log_m, a, s);
+            a.pw_scale = to_table_form(to_table_form(pl->ninv_plain % pl->p, pl->p, pl->word_bytes), pl->p, pl->word_bytes);
+            hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_product_mid(first.log_m, a, s)
+                                               : ntt::launch_m32_product_mid(first.log_m, a, s);
             if (e != hipSuccess) return (int) e;
         }
         for (size_t i = 1; i < pl->passes.size(); i++) {
@@ -582,7 +586,8 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
             ntt::ErasedArgs a = base_args(pl, pd, d_out, d_out, batch);
             a.tw = pl->d_tw_fwd;
             a.layout = NTT_LAYOUT_NATURAL;
-            hipError_t e = ntt::launch_gl_fwd(pd.contig, pd.log_m, a, s);
+            hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_fwd(pd.contig, pd.log_m, a, s)
+                                               : ntt::launch_m32_fwd(pd.contig, pd.log_m, a, s);
             if (e != hipSuccess) return (int) e;
         }
         return NTT_OK;

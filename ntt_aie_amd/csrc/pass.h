@@ -944,7 +944,8 @@ NTT_HD void tw_table_read(Ctx<Cfg> &c, const typename Cfg::W *table) {
 // CI = the inverse CONTIG configuration, CF = the forward one (non-DMA), same LOG_M / LOG_E / LOG_NT.
 // Exec: eachI(fn(Ctx<CI>&)), eachF(fn(Ctx<CF>&)), eachIF(fn(Ctx<CI>&, Ctx<CF>&, W *keep, W *pre)), sync(), lds(), pg_base(),
 // tabI() / tabF(): the LDS twiddle tables of the two directions (tw_table_words<C>() words each).
-template <class CI, class CF, class Exec>
+// M32_MODE: which 4-byte-word instruction stream the butterflies run (see phase_compute); ignored by Goldilocks.
+template <class CI, class CF, class Exec, int M32_MODE = -1>
 NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI> &ab, const PassArgs<CF> &af) {
     using W = typename CI::W;
     static_assert(CI::CONTIG && CF::CONTIG && CI::INV && !CF::INV, "middle of the product: inverse CONTIG then forward CONTIG");
@@ -969,7 +970,7 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
         static_for<0, R>([&](auto kk) {
             constexpr int r = R - 1 - decltype(kk)::value;
             if constexpr (!CI::preload(r)) ex.eachI([&](Ctx<CI> &c) { tw_table_read<CI, r>(c, ex.tabI()); });
-            ex.eachI([&](Ctx<CI> &c) { phase_compute<CI, r, -1, true>(c, a); });
+            ex.eachI([&](Ctx<CI> &c) { phase_compute<CI, r, M32_MODE, true>(c, a); });
             if constexpr (r > 0) {
                 ex.eachI([&](Ctx<CI> &c) { phase_lds_write<CI, r>(c, tile); });
                 ex.sync(WL{});
@@ -1039,7 +1040,7 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
         static_for<0, R>([&](auto kk) {
             constexpr int r = decltype(kk)::value;
             if constexpr (!CF::preload(r)) ex.eachF([&](Ctx<CF> &c) { tw_table_read<CF, r>(c, ex.tabF()); });
-            ex.eachF([&](Ctx<CF> &c) { phase_compute<CF, r, -1, true>(c, af); });
+            ex.eachF([&](Ctx<CF> &c) { phase_compute<CF, r, M32_MODE, true>(c, af); });
             if constexpr (r < R - 1) {
                 ex.eachF([&](Ctx<CF> &c) { phase_lds_write<CF, r>(c, tile); });
                 ex.sync(WL{});
@@ -1066,6 +1067,14 @@ struct ProductCfg {
     static constexpr bool UNIFORM_TOP = LOG_NT + 3 - LOG_M == 0;  // one unit per workgroup
     using CI = PassCfg<FieldGL, LOG_M, 0, true, true, NTT_PRODUCT_MASK(R, UNIFORM_TOP), 3, LOG_NT, false>;
     using CF = PassCfg<FieldGL, LOG_M, 0, true, false, NTT_PRODUCT_MASK(R, UNIFORM_TOP), 3, LOG_NT, false>;
+};
+
+// 4-byte words: radix-16 rounds in 256-thread workgroups (the shape of every 4-byte CONTIG pass), unit sizes 2^5 .. 2^12
+// (two rounds at least); only the innermost round's twiddles stay in registers, the others come from the LDS table.
+template <int LOG_M>
+struct ProductCfgM32 {
+    using CI = PassCfg<FieldM32, LOG_M, 0, true, true, 1, 4, 8, false>;
+    using CF = PassCfg<FieldM32, LOG_M, 0, true, false, 1, 4, 8, false>;
 };
 
 // ---- launch geometry shared by host planner and host model ---------------------

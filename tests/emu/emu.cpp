@@ -79,48 +79,6 @@ struct EmuProductExec {
     W *tabF() { return tab_f.data(); }
 };
 
-template <int LOG_M>
-int run_product_mid(int n, uint32_t batch, uint32_t target_wgs, const uint64_t *a_in, const uint64_t *b_in, uint64_t *out,
-                    const uint64_t *tw_inv, const uint64_t *tw_fwd, uint64_t pw_scale) {
-    using CI = typename ProductCfg<LOG_M>::CI;
-    using CF = typename ProductCfg<LOG_M>::CF;
-    PassGeom g = pass_geometry(n, 0, LOG_M, 0, CI::LOG_U, true, batch, target_wgs);
-    PassArgs<CI> aa;
-    memset((void *) &aa, 0, sizeof(aa));
-    aa.in = a_in;
-    aa.tw = tw_inv;
-    aa.n = n;
-    aa.batch = batch;
-    aa.ppw = g.ppw;
-    aa.log_ul = g.log_ul;
-    aa.log_uh = g.log_uh;
-    aa.log_up = g.log_up;
-    aa.pg_stride = 1;
-    PassArgs<CI> ab = aa;
-    ab.in = b_in;
-    PassArgs<CF> af;
-    memset((void *) &af, 0, sizeof(af));
-    af.out = out;
-    af.tw = tw_fwd;
-    af.n = n;
-    af.batch = batch;
-    af.ppw = g.ppw;
-    af.log_ul = g.log_ul;
-    af.log_uh = g.log_uh;
-    af.log_up = g.log_up;
-    af.pg_stride = 1;
-    af.pw_scale = pw_scale;
-    EmuProductExec<CI, CF> ex;
-    for (uint32_t by = 0; by < g.grid_y; by++)
-        for (uint32_t bx = 0; bx < g.grid_x; bx++) {
-            ex.bx = bx;
-            ex.by = by;
-            memset(ex.tile.data(), 0xA5, ex.tile.size() * sizeof(uint64_t));
-            run_product_pass<CI, CF>(ex, aa, ab, af);
-        }
-    return 0;
-}
-
 struct Erased {
     const void *in;
     void *out;
@@ -145,6 +103,55 @@ template <>
 FieldM32 make_field<FieldM32>(const Erased &e) {
     return FieldM32{e.p, e.pinv, e.r2};
 }
+
+template <class PC>
+int run_product_mid(int n, uint32_t batch, uint32_t target_wgs, const void *a_in_, const void *b_in_, void *out_,
+                    const void *tw_inv_, const void *tw_fwd_, uint64_t pw_scale, const Erased &fe) {
+    using CI = typename PC::CI;
+    using CF = typename PC::CF;
+    using W = typename CI::W;
+    constexpr int LOG_M = CI::LOG_M;
+    const W *a_in = (const W *) a_in_, *b_in = (const W *) b_in_, *tw_inv = (const W *) tw_inv_, *tw_fwd = (const W *) tw_fwd_;
+    W *out = (W *) out_;
+    PassGeom g = pass_geometry(n, 0, LOG_M, 0, CI::LOG_U, true, batch, target_wgs);
+    PassArgs<CI> aa;
+    memset((void *) &aa, 0, sizeof(aa));
+    aa.in = a_in;
+    aa.tw = tw_inv;
+    aa.field = make_field<typename CI::F>(fe);
+    aa.n = n;
+    aa.batch = batch;
+    aa.ppw = g.ppw;
+    aa.log_ul = g.log_ul;
+    aa.log_uh = g.log_uh;
+    aa.log_up = g.log_up;
+    aa.pg_stride = 1;
+    PassArgs<CI> ab = aa;
+    ab.in = b_in;
+    PassArgs<CF> af;
+    memset((void *) &af, 0, sizeof(af));
+    af.out = out;
+    af.tw = tw_fwd;
+    af.field = make_field<typename CF::F>(fe);
+    af.n = n;
+    af.batch = batch;
+    af.ppw = g.ppw;
+    af.log_ul = g.log_ul;
+    af.log_uh = g.log_uh;
+    af.log_up = g.log_up;
+    af.pg_stride = 1;
+    af.pw_scale = (W) pw_scale;
+    EmuProductExec<CI, CF> ex;
+    for (uint32_t by = 0; by < g.grid_y; by++)
+        for (uint32_t bx = 0; bx < g.grid_x; bx++) {
+            ex.bx = bx;
+            ex.by = by;
+            memset(ex.tile.data(), 0xA5, ex.tile.size() * sizeof(W));
+            run_product_pass<CI, CF>(ex, aa, ab, af);
+        }
+    return 0;
+}
+
 
 template <class Cfg>
 int run_cfg(const Erased &e) {
@@ -344,23 +351,36 @@ int emu_forward_product(int word_bytes, int logn, uint64_t p, const void *T_plai
     return 0;
 }
 
-// The negacyclic product c = Fwd(InvU(a) . InvU(b) . N^-1) the way ntt_polymul_negacyclic runs it for multi-pass Goldilocks
-// sizes: inverse column passes of both operands, the fused middle pass (pass.h: run_product_pass), forward column passes.
-// T_plain is the kind-2 table; a and b are overwritten (scratch), like on the device.
-int emu_polymul_fused(int logn, const void *T_plain, void *a, void *b, void *out, uint32_t batch, uint32_t target_wgs) {
-    const uint64_t p = GOLDILOCKS;
+// The negacyclic product c = Fwd(InvU(a) . InvU(b) . N^-1) the way ntt_polymul_negacyclic runs it when the first pass
+// has a product kernel: inverse column passes of both operands, the fused middle pass (pass.h: run_product_pass; the
+// whole product for a single-pass size), forward column passes.  T_plain is the kind-2 table; a and b are overwritten
+// (scratch), like on the device.
+int emu_polymul_fused(int word_bytes, int logn, uint64_t p, const void *T_plain, void *a, void *b, void *out, uint32_t batch,
+                      uint32_t target_wgs) {
     const size_t N = (size_t) 1 << logn;
-    std::vector<uint64_t> T(N), Ti, tf(N), ti(N);
-    for (size_t i = 0; i < N; i++) T[i] = ((const uint64_t *) T_plain)[i];
+    std::vector<uint64_t> T(N), Ti;
+    for (size_t i = 0; i < N; i++) T[i] = word_bytes == 4 ? ((const uint32_t *) T_plain)[i] : ((const uint64_t *) T_plain)[i];
     if (!invert_table(T, p, Ti)) return -5;
+    std::vector<uint64_t> tf64(N), ti64(N);
+    std::vector<uint32_t> tf32(N), ti32(N);
     for (size_t i = 0; i < N; i++) {
-        tf[i] = to_table_form(T[i], p, 8);
-        ti[i] = to_table_form(Ti[i], p, 8);
+        tf64[i] = to_table_form(T[i], p, word_bytes);
+        ti64[i] = to_table_form(Ti[i], p, word_bytes);
+        tf32[i] = (uint32_t) tf64[i];
+        ti32[i] = (uint32_t) ti64[i];
     }
-    const std::vector<PassDesc> passes = plan_passes(logn, 8);
-    if (passes[0].log_m < 7 || passes[0].log_m > 12) return -1;  // unit sizes the product kernel exists for
+    const void *tf = word_bytes == 4 ? (const void *) tf32.data() : (const void *) tf64.data();
+    const void *ti = word_bytes == 4 ? (const void *) ti32.data() : (const void *) ti64.data();
+    const std::vector<PassDesc> passes = plan_passes(logn, word_bytes);
+    const int m0 = passes[0].log_m;
+    if (word_bytes == 8 ? (m0 < 7 || m0 > 12) : (m0 < 5 || m0 > 12)) return -1;  // unit sizes the product kernels exist for
     Erased e;
     memset(&e, 0, sizeof(e));
+    e.p = (uint32_t) p;
+    if (word_bytes == 4) {
+        e.pinv = mont_pinv((uint32_t) p);
+        e.r2 = mont_r2((uint32_t) p);
+    }
     e.n = logn;
     e.batch = batch;
     e.target_wgs = target_wgs;
@@ -368,27 +388,38 @@ int emu_polymul_fused(int logn, const void *T_plain, void *a, void *b, void *out
         for (void *buf : {a, b}) {
             e.in = buf;
             e.out = buf;
-            e.tw = ti.data();
+            e.tw = ti;
             e.s0 = passes[i].s0;
-            const int rc = dispatch<FieldGL, true>(passes[i].contig, passes[i].log_m, e);
+            const int rc = word_bytes == 8 ? dispatch<FieldGL, true>(passes[i].contig, passes[i].log_m, e)
+                                           : dispatch<FieldM32, true>(passes[i].contig, passes[i].log_m, e);
             if (rc) return rc;
         }
     const uint64_t ninv = powmod((p + 1) / 2, (uint64_t) logn, p);
-    const uint64_t pw = to_table_form(to_table_form(ninv, p, 8), p, 8);
+    const uint64_t pw = to_table_form(to_table_form(ninv, p, word_bytes), p, word_bytes);
     int rc = -1;
-    switch (passes[0].log_m) {
-#define PM(M) case M: rc = run_product_mid<M>(logn, batch, target_wgs, (const uint64_t *) a, (const uint64_t *) b, (uint64_t *) out, ti.data(), tf.data(), pw); break;
-        PM(7) PM(8) PM(9) PM(10) PM(11) PM(12)
+    if (word_bytes == 8) {
+        switch (m0) {
+#define PM(M) case M: rc = run_product_mid<ProductCfg<M>>(logn, batch, target_wgs, a, b, out, ti, tf, pw, e); break;
+            PM(7) PM(8) PM(9) PM(10) PM(11) PM(12)
 #undef PM
-        default: return -1;
+            default: return -1;
+        }
+    } else {
+        switch (m0) {
+#define PM(M) case M: rc = run_product_mid<ProductCfgM32<M>>(logn, batch, target_wgs, a, b, out, ti, tf, pw, e); break;
+            PM(5) PM(6) PM(7) PM(8) PM(9) PM(10) PM(11) PM(12)
+#undef PM
+            default: return -1;
+        }
     }
     if (rc) return rc;
     for (size_t i = 1; i < passes.size(); i++) {
         e.in = out;
         e.out = out;
-        e.tw = tf.data();
+        e.tw = tf;
         e.s0 = passes[i].s0;
-        rc = dispatch<FieldGL, false>(passes[i].contig, passes[i].log_m, e);
+        rc = word_bytes == 8 ? dispatch<FieldGL, false>(passes[i].contig, passes[i].log_m, e)
+                             : dispatch<FieldM32, false>(passes[i].contig, passes[i].log_m, e);
         if (rc) return rc;
     }
     return 0;

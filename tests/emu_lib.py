@@ -22,7 +22,7 @@ def lib():
                                     C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint64]
         L.emu_forward_product.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_uint32, C.c_uint64, C.c_uint32]
-        L.emu_polymul_fused.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.emu_polymul_fused.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.emu_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
         for n in ("emu_gl_mul", "emu_gl_add", "emu_gl_sub"):
             getattr(L, n).restype = C.c_uint64

@@ -122,31 +122,34 @@ def test_fused_pointwise_first_pass(oracle):
             assert np.array_equal(out, oracle.ntt(oracle.pointwise(a, b, p, scale), T, p)), (wb, logn)
 
 
-@pytest.mark.parametrize("logn", [7, 9, 10, 12, 13, 14, 16, 17, 18, 19, 20])  # whole product in one pass (N <= 2^12); fused middle of 7 ... 12 stages
-def test_product_fused_middle_pass(oracle, logn):
-    """The negacyclic product the way the device runs it for multi-pass Goldilocks sizes (pass.h: run_product_pass: last
-    inverse pass of both operands + pointwise + first forward pass per workgroup-resident unit, LDS twiddle tables,
-    register prefetch of operand b), in the host index model, against the oracle pipeline.  target_wgs 8 makes the
-    workgroups stream several polynomials (the batch loop and its prefetch hand-over)."""
-    p = GOLD
+@pytest.mark.parametrize("wb,p,g,logn", [(8, GOLD, 7, l) for l in (7, 9, 10, 12, 13, 14, 16, 17, 18, 19, 20)] +
+                         [(4, 998244353, 3, l) for l in (5, 6, 8, 10, 11, 12, 13, 16, 17, 19)] +
+                         [(4, 2013265921, 31, 9), (4, 3221225473, 5, 7), (4, 3221225473, 5, 12), (4, 3221225473, 5, 14)])
+def test_product_fused_middle_pass(oracle, wb, p, g, logn):
+    """The negacyclic product the way the device runs it when the first pass has a product kernel (pass.h: run_product_pass:
+    last inverse pass of both operands + pointwise + first forward pass per workgroup-resident unit -- the whole product for
+    N <= 2^12 --, LDS twiddle tables, register prefetch of operand b), in the host index model, against the oracle pipeline.
+    Goldilocks radix-8 units of 2^7..2^12 words and 4-byte-word radix-16 units of 2^5..2^12 (lazy, 31-bit and 32-bit moduli).
+    target_wgs 8 makes the workgroups stream several polynomials (the batch loop and its prefetch hand-over)."""
+    dt = np.uint32 if wb == 4 else np.uint64
     n = 1 << logn
     batch = 37 if logn <= 12 else (3 if logn <= 17 else 2)  # small N: several polynomials per workgroup, ragged tail
-    T = oracle.make_table(2, n, p, 7)
+    T = oracle.make_table(2, n, p, g, wb)
     rng = np.random.default_rng(logn)
-    a = rng.integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p)
-    b = rng.integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p)
+    a = (rng.integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p)).astype(dt)
+    b = (rng.integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p)).astype(dt)
     a[0, :3] = [p - 1, 0, 1]
     b[0, :3] = [p - 1, p - 1, 0]
     A, B = oracle.intt(a, T, p, nthreads=4), oracle.intt(b, T, p, nthreads=4)
     want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p, nthreads=4)
     sa, sb, out = a.copy(), b.copy(), np.zeros_like(a)
-    rc = emu_lib.lib().emu_polymul_fused(logn, T.ctypes.data, sa.ctypes.data, sb.ctypes.data, out.ctypes.data, batch, 8)
+    rc = emu_lib.lib().emu_polymul_fused(wb, logn, p, T.ctypes.data, sa.ctypes.data, sb.ctypes.data, out.ctypes.data, batch, 8)
     assert rc == 0
-    assert np.array_equal(out, want), logn
+    assert np.array_equal(out, want), (wb, p, logn)
     # in place into the first operand, as the Python host does by default
     sa, sb = a.copy(), b.copy()
-    assert emu_lib.lib().emu_polymul_fused(logn, T.ctypes.data, sa.ctypes.data, sb.ctypes.data, sa.ctypes.data, batch, 8) == 0
-    assert np.array_equal(sa, want), logn
+    assert emu_lib.lib().emu_polymul_fused(wb, logn, p, T.ctypes.data, sa.ctypes.data, sb.ctypes.data, sa.ctypes.data, batch, 8) == 0
+    assert np.array_equal(sa, want), (wb, p, logn)
 
 
 def test_composite_odd_modulus(oracle):

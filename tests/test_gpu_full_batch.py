@@ -218,3 +218,28 @@ def test_single_pass_product_one_launch(eng, oracle, logn, batch):
     one = torch.zeros_like(b)
     one[:, 0] = 1
     assert torch.equal(pl.polymul_negacyclic(a.clone(), one), a)
+
+
+@pytest.mark.parametrize("p,g", [(998244353, 3), (3221225473, 5)])
+@pytest.mark.parametrize("logn,batch", [(6, 300007), (12, 16384), (16, 2048), (20, 64)])
+def test_product_four_byte_words_full_batch(eng, oracle, p, g, logn, batch):
+    """The product kernel for 4-byte words (kernels_m32_product.hip): one launch for N <= 2^12 (several polynomials per
+    workgroup, ragged tail), fused middle + column passes above; lazy and carry-select butterfly streams."""
+    import torch
+
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, 4, 0)
+    T = pl.make_table(2, g)
+    pl.set_twiddles(T)
+    a = _device_batch(torch, batch, n, p, 4, logn)
+    b = _device_batch(torch, batch, n, p, 4, logn + 7)
+    rows = [0, 1, batch // 2, batch - 2, batch - 1]
+    ah, bh = eng.to_host(a[rows]), eng.to_host(b[rows])
+    A, B = oracle.intt(ah, T, p, nthreads=4), oracle.intt(bh, T, p, nthreads=4)
+    want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p, nthreads=4)
+    c = pl.polymul_negacyclic(a.clone(), b.clone())
+    assert np.array_equal(eng.to_host(c[rows]), want)
+    assert pl.count_noncanonical(c) == 0
+    one = torch.zeros_like(b)
+    one[:, 0] = 1
+    assert torch.equal(pl.polymul_negacyclic(a.clone(), one), a)

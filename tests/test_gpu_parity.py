@@ -159,9 +159,10 @@ def test_error_paths(eng):
 
 
 def test_pointwise_and_negacyclic_polymul(eng, oracle):
-    for wb, p, g in [(8, GOLD, 7), (4, 998244353, 3)]:
+    # 4-byte words: a lazy (< 2^30), a 31-bit and a 32-bit prime = the three butterfly streams of the product kernel (N >= 2^5)
+    for wb, p, g in [(8, GOLD, 7), (4, 998244353, 3), (4, 2013265921, 31), (4, 3221225473, 5)]:
         dt = np.uint32 if wb == 4 else np.uint64
-        for logn in (2, 4, 6, 7, 8, 9, 11, 12, 13):  # Goldilocks 7..12: the whole product is ONE launch of the radix-8 product kernel
+        for logn in (2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 16):  # Goldilocks 7..12: the whole product is ONE launch of the radix-8 product kernel
             n = 1 << logn
             pl = eng.NTTPlan(logn, p, wb, 0)
             T = pl.make_table(2, g)
