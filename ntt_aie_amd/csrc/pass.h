@@ -51,6 +51,9 @@
 #define NTT_COL_DMA 0  // experiment knob: LDS-DMA prefetch in the 8-stage Goldilocks column pass, ONE tile buffer (the next
                        // tile lands in it while the second round computes); measured in DESIGN.md section 8.5
 #endif
+#ifndef NTT_PRODUCT_TW_EARLY
+#define NTT_PRODUCT_TW_EARLY 1  // product pass: read the next round's LDS-table twiddles before the exchange barrier (measured -0.5 .. -0.9 %)
+#endif
 #ifndef NTT_PRODUCT_PREFETCH_A
 #define NTT_PRODUCT_PREFETCH_A 0  // product pass: also prefetch the NEXT unit's operand a during the forward rounds (b is always prefetched)
 #endif
@@ -969,10 +972,13 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
     auto inverse_unit = [&](const PassArgs<CI> &a, W *tile) {  // on the words already in ci.x
         static_for<0, R>([&](auto kk) {
             constexpr int r = R - 1 - decltype(kk)::value;
-            if constexpr (!CI::preload(r)) ex.eachI([&](Ctx<CI> &c) { tw_table_read<CI, r>(c, ex.tabI()); });
+            if constexpr (!CI::preload(r) && (!NTT_PRODUCT_TW_EARLY || r == R - 1))
+                ex.eachI([&](Ctx<CI> &c) { tw_table_read<CI, r>(c, ex.tabI()); });
             ex.eachI([&](Ctx<CI> &c) { phase_compute<CI, r, M32_MODE, true>(c, a); });
             if constexpr (r > 0) {
                 ex.eachI([&](Ctx<CI> &c) { phase_lds_write<CI, r>(c, tile); });
+                // the next round's twiddles are requested from the LDS table before the barrier: their latency overlaps the wait
+                if constexpr (NTT_PRODUCT_TW_EARLY && !CI::preload(r - 1)) ex.eachI([&](Ctx<CI> &c) { tw_table_read<CI, r - 1>(c, ex.tabI()); });
                 ex.sync(WL{});
                 ex.eachI([&](Ctx<CI> &c) { phase_lds_read<CI, r - 1>(c, tile); });
             }
@@ -1039,10 +1045,12 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
         // no barrier here: the forward rounds first WRITE the round-0 positions, which this thread itself read last
         static_for<0, R>([&](auto kk) {
             constexpr int r = decltype(kk)::value;
-            if constexpr (!CF::preload(r)) ex.eachF([&](Ctx<CF> &c) { tw_table_read<CF, r>(c, ex.tabF()); });
+            if constexpr (!CF::preload(r) && (!NTT_PRODUCT_TW_EARLY || r == 0))
+                ex.eachF([&](Ctx<CF> &c) { tw_table_read<CF, r>(c, ex.tabF()); });
             ex.eachF([&](Ctx<CF> &c) { phase_compute<CF, r, M32_MODE, true>(c, af); });
             if constexpr (r < R - 1) {
                 ex.eachF([&](Ctx<CF> &c) { phase_lds_write<CF, r>(c, tile); });
+                if constexpr (NTT_PRODUCT_TW_EARLY && !CF::preload(r + 1)) ex.eachF([&](Ctx<CF> &c) { tw_table_read<CF, r + 1>(c, ex.tabF()); });
                 ex.sync(WL{});
                 ex.eachF([&](Ctx<CF> &c) { phase_lds_read<CF, r + 1>(c, tile); });
             }
