@@ -548,8 +548,15 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
     // Goldilocks, first (or only) pass of 7..12 stages: the radix-8 product kernel exists for that unit size.  A single-pass
     // size (2^7 <= N <= 2^12) is then ONE launch for the whole product: read a, read b, write c.
     // ... 4-byte words: radix-16 product kernel, unit sizes 2^5 .. 2^12 (any odd p: all three butterfly streams).
-    const bool fused_mid = first.contig && (pl->word_bytes == 8 ? ntt::have_gl_product_mid(first.log_m)
-                                                                 : ntt::have_m32_product_mid(first.log_m));
+    bool fused_mid = first.contig && (pl->word_bytes == 8 ? ntt::have_gl_product_mid(first.log_m)
+                                                           : ntt::have_m32_product_mid(first.log_m));
+    if (fused_mid) {
+        // the product launch is not sliced: beyond blockIdx.y's range (tens of millions of tiny polynomials) take the
+        // separate passes, whose launcher slices the batch
+        const int log_u = pl->word_bytes == 8 ? ((first.log_m >= 10 ? 9 : 8) + 3 - first.log_m) : (12 - first.log_m);
+        const ntt::PassGeom g = ntt::pass_geometry(pl->logn, 0, first.log_m, 0, log_u, true, batch, pl->target_wgs);
+        if (g.grid_y > 65535u) fused_mid = false;
+    }
     if (fused_mid) {
         // The column passes (if any) of both unscaled inverse transforms, then ONE launch that runs
         // the last inverse pass of a and of b, the pointwise product * N^-1 and the first forward pass on each
