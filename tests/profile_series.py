@@ -10,7 +10,8 @@ engine beside the AIE and the A100 (profile/plot_efficiency.py:25-27,44-46, prof
   profiles/exectime/ntt_mi355x_logn{8..13}.csv   the reference's 10-launch test procedure (host.reference_procedure: launch +
                                           wait, wall clock, one integer microsecond per line), verified against the oracle
 
-Run on the GPU box: python3 tools/profile_series.py [outdir]   (default gpurun_out/profiles_series; copy into profiles/)."""
+Lives under tests/ because it uses the oracle as the checker of the reference procedure (only tests/, smoke() and bench.py's
+cpu_baseline may touch oracle/).  Run on the GPU box: python3 tests/profile_series.py [outdir]   (default gpurun_out/profiles_series; copy into profiles/)."""
 import os
 import statistics
 import sys
