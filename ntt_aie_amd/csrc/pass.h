@@ -47,6 +47,12 @@
 #ifndef NTT_LATE_SYNC
 #define NTT_LATE_SYNC 0  // experiment knob: end-of-iteration barrier moved to before the next iteration's first LDS write (measured: column pass +2 %, worse)
 #endif
+#ifndef NTT_PPW_CAP_CONTIG_INV
+#define NTT_PPW_CAP_CONTIG_INV 8  // cap on polynomials per workgroup, inverse radix-8 CONTIG passes (see PassCfg::PPW_CAP)
+#endif
+#ifndef NTT_PPW_CAP_COL_INV
+#define NTT_PPW_CAP_COL_INV 4  // ... inverse Goldilocks column passes
+#endif
 #ifndef NTT_COL_DMA
 #define NTT_COL_DMA 0  // experiment knob: LDS-DMA prefetch in the 8-stage Goldilocks column pass, ONE tile buffer (the next
                        // tile lands in it while the second round computes); measured in DESIGN.md section 8.5
@@ -145,6 +151,12 @@ struct PassCfg {
                                          (NTT_INV_PREFETCH && CONTIG && INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8);
 
     static constexpr int LDS_WORDS = CDMA ? TILE_WORDS + (TILE_WORDS >> 8) * 16 : LDS_WORDS_PADDED;
+    // Most polynomials a workgroup streams through its resident twiddles (tools/ppw_sweep.py, N = 2^13 .. 2^17, batches
+    // 2048 .. 16384): the 256-thread Goldilocks LDS-DMA first passes are fastest at 8 whatever the batch (16 costs 5-6 % at
+    // batch 8192), the Goldilocks column passes at 4 (8 costs 4 %); the other kernels keep the workgroup-count rule alone.
+    static constexpr int PPW_CAP = sizeof(W) == 8 ? (CONTIG ? (LOG_E_ < 4 && LOG_NT_ == 8 ? (INV ? NTT_PPW_CAP_CONTIG_INV : 8) : 64)
+                                                              : (INV ? NTT_PPW_CAP_COL_INV : 4))
+                                                   : 64;
     static NTT_HD uint32_t lds_index(uint32_t lin) {
         if (CDMA) return lin + ((lin >> 8) << 4);  // 16 words after every 16 rows of 16 words
         return DMA ? lin : lin + ((lin >> LOG_E) * VW);
@@ -1094,7 +1106,7 @@ struct PassGeom {
 
 // n = log2 N, pass covers stages [s0, s0 + log_m); log_c columns; log_u units per WG
 inline PassGeom pass_geometry(int n, int s0, int log_m, int log_c, int log_u, bool contig,
-                              uint64_t batch, uint32_t target_wgs) {
+                              uint64_t batch, uint32_t target_wgs, int ppw_cap = 64) {
     PassGeom g;
     const int log_h = n - s0 - log_m;              // hi values per polynomial
     const int log_lt = contig ? 0 : s0 - log_c;    // lo tiles per (poly, hi)
@@ -1107,7 +1119,7 @@ inline PassGeom pass_geometry(int n, int s0, int log_m, int log_c, int log_u, bo
     // stream several polynomials through one workgroup (twiddles stay in registers)
     // but keep at least target_wgs workgroups in flight
     uint64_t ppw = 1;
-    while (ppw < 64 && (uint64_t) g.grid_x * ((poly_groups + 2 * ppw - 1) / (2 * ppw)) >= target_wgs) ppw *= 2;
+    while (ppw < (uint64_t) ppw_cap && (uint64_t) g.grid_x * ((poly_groups + 2 * ppw - 1) / (2 * ppw)) >= target_wgs) ppw *= 2;
     g.ppw = (int) ppw;
     uint64_t gy = (poly_groups + ppw - 1) / ppw;
     g.grid_y = (uint32_t) gy;

@@ -172,7 +172,7 @@ int run_cfg(const Erased &e) {
     a.in2 = (const W *) e.in2;
     a.pw_scale = (W) e.pw_scale;
     a.skip_if = nullptr;
-    PassGeom g = pass_geometry(e.n, e.s0, Cfg::LOG_M, Cfg::LOG_C, Cfg::LOG_U, Cfg::CONTIG, e.batch, e.target_wgs);
+    PassGeom g = pass_geometry(e.n, e.s0, Cfg::LOG_M, Cfg::LOG_C, Cfg::LOG_U, Cfg::CONTIG, e.batch, e.target_wgs, Cfg::PPW_CAP);
     a.ppw = g.ppw;
     a.log_ul = g.log_ul;
     a.log_uh = g.log_uh;

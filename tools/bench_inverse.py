@@ -7,7 +7,7 @@ import torch
 from bench import GOLDILOCKS, synth_batch
 from ntt_aie_amd import NTTPlan
 torch.cuda.set_device(0)
-for logn, batch in ((16, 4096), (13, 32768), (20, 256)):
+for logn, batch in ((16, 4096), (16, 8192), (16, 16384), (13, 65536)):
     plan = NTTPlan(logn, GOLDILOCKS, 8, 0); plan.generate_twiddles(0, 7)
     x = synth_batch(torch, batch, 1 << logn, torch.device("cuda", 0)); y = torch.empty_like(x)
     for _ in range(10): plan.inverse(x, y)
