@@ -243,3 +243,23 @@ def test_product_four_byte_words_full_batch(eng, oracle, p, g, logn, batch):
     one = torch.zeros_like(b)
     one[:, 0] = 1
     assert torch.equal(pl.polymul_negacyclic(a.clone(), one), a)
+
+
+def test_column_pass_beyond_grid_limit_is_sliced(eng, oracle):
+    """With at most 4 polynomials per column-pass workgroup, N = 2^13 at batch 263140 needs more than 65535 rows of
+    workgroups: the launcher slices the batch (pass_kernel.inc: launch_cfg).  17 GB per buffer; sampled rows on both sides
+    of every slice boundary against the oracle, the whole batch by round trip."""
+    import torch
+
+    p, logn = GOLD, 13
+    n = 1 << logn
+    batch = 65535 * 4 + 1000
+    pl = eng.NTTPlan(logn, p, 8, 0)
+    T = pl.make_roots(7)
+    pl.set_twiddles(T)
+    x = _device_batch(torch, batch, n, p, 8, 13)
+    X = pl.forward(x)
+    rows = [0, 1, 65535 * 4 - 1, 65535 * 4, 65535 * 4 + 1, batch - 1]
+    assert np.array_equal(eng.to_host(X[rows]), oracle.ntt(eng.to_host(x[rows]), T, p, nthreads=4))
+    back = pl.inverse(X)
+    assert torch.equal(back, x)
