@@ -304,6 +304,11 @@ constexpr bool tw_uniform() {
 }
 
 // ---- phases -------------------------------------------------------------------
+template <class W, int V>
+struct alignas(sizeof(W) * V) Chunk {
+    W v[V];
+};
+
 template <class Cfg, int r>
 NTT_HD void load_twiddles(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
     constexpr int b0 = Cfg::win(r);
@@ -316,9 +321,23 @@ NTT_HD void load_twiddles(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
         const int s = a.s0 + m;
         const uint32_t base = (1u << (a.n - s - 1)) + (c.hi << (Cfg::LOG_M - m - 1)) +
                               (q_hi << (Cfg::LOG_E - t - 1));
+        // the cnt entries of a stage are consecutive and `base` is a multiple of cnt (every term is a multiple of
+        // 2^(LOG_E-t-1)): fetch them in 16-byte pieces where there are that many (5 requests per round instead of 15)
+        constexpr int TV = cnt * (int) sizeof(typename Cfg::W) >= 16 ? 16 / (int) sizeof(typename Cfg::W) : cnt;
+        typename Cfg::W tv[cnt];
+#pragma unroll
+        for (int k = 0; k < cnt; k += TV) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const Chunk<typename Cfg::W, TV> ch = *reinterpret_cast<const Chunk<typename Cfg::W, TV> *>(a.tw + base + k);
+#pragma unroll
+            for (int i = 0; i < TV; ++i) tv[k + i] = ch.v[i];
+#else
+            for (int i = 0; i < TV; ++i) tv[k + i] = a.tw[base + k + i];
+#endif
+        }
 #pragma unroll
         for (int k = 0; k < cnt; ++k) {
-            typename Cfg::W v = a.tw[base + k];
+            typename Cfg::W v = tv[k];
 #if defined(__HIP_DEVICE_COMPILE__)
             if constexpr (tw_uniform<Cfg, r>() && sizeof(typename Cfg::W) == 8) {
                 const uint32_t v0 = __builtin_amdgcn_readfirstlane((uint32_t) v);
@@ -331,7 +350,17 @@ NTT_HD void load_twiddles(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
     });
 }
 
+// the twiddles that stay in registers across the batch loop (PassCfg::PRELOAD_MASK)
 template <class Cfg>
+NTT_HD void phase_init_twiddles(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
+    static_for<0, Cfg::R>([&](auto rr) {
+        if constexpr (Cfg::preload(decltype(rr)::value)) load_twiddles<Cfg, decltype(rr)::value>(c, a);
+    });
+}
+
+// WITH_TW = false: index registers only; the caller issues the first tile's loads and then calls
+// phase_init_twiddles() itself, so that the coefficient loads are the oldest requests in flight (run_pass, EARLY_LOAD)
+template <class Cfg, bool WITH_TW = true>
 NTT_HD void phase_init(Ctx<Cfg> &c, const PassArgs<Cfg> &a, uint32_t tid, uint32_t bx, uint32_t by) {
     c.tid = tid;
     c.bx = bx;
@@ -359,9 +388,7 @@ NTT_HD void phase_init(Ctx<Cfg> &c, const PassArgs<Cfg> &a, uint32_t tid, uint32
         const uint32_t mid0 = (q_hi << (b0 + Cfg::LOG_E)) | q_lo;
         c.lds_base[r] = Cfg::lds_index((((u << Cfg::LOG_M) | mid0) << Cfg::LOG_C) | col);
     });
-    static_for<0, Cfg::R>([&](auto rr) {
-        if constexpr (Cfg::preload(decltype(rr)::value)) load_twiddles<Cfg, decltype(rr)::value>(c, a);
-    });
+    if constexpr (WITH_TW) phase_init_twiddles<Cfg>(c, a);
 }
 
 template <class Cfg>
@@ -511,52 +538,140 @@ NTT_HD void phase_store_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
 #endif
 }
 
-template <class W, int V>
-struct alignas(sizeof(W) * V) Chunk {
-    W v[V];
-};
-
 // CONTIG only.  The workgroup's units are consecutive hi values of one polynomial
 // or, when a polynomial has fewer units than the workgroup, whole consecutive
 // polynomials: either way TILE_WORDS contiguous words of the [batch][N] buffer.
-// Move them between HBM and LDS in 16-byte chunks, lanes along consecutive chunks.
-template <class Cfg, bool TO_LDS>
-NTT_HD void phase_linear(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *lds, int it) {
+// Move them between HBM and LDS in 16-byte chunks, lanes along consecutive chunks;
+// wave w stages its own contiguous 64*E words: 1 KiB per wave-instruction.
+template <class Cfg>
+struct LinearGeom {
     using W = typename Cfg::W;
-    constexpr int V = Cfg::E < Cfg::VW ? Cfg::E : Cfg::VW;  // words per chunk
-    constexpr int ITER = Cfg::E / V;
+    static constexpr int V = Cfg::E < Cfg::VW ? Cfg::E : Cfg::VW;  // words per chunk
+    static constexpr int ITER = Cfg::E / V;
+    static constexpr uint32_t STEP = 64 * V;  // multiple of E: pad term is linear in i
     using Ch = Chunk<W, V>;
-    const size_t tile0 = uniform_word<Cfg>(c, a, it);
-    const uint32_t pg0 = (c.pg_base + (uint32_t) it * (uint32_t) a.pg_stride) << a.log_up;
-    // wave w stages its own contiguous 64*E words: 1 KiB per wave-instruction, lanes along chunks
-    const uint32_t wbase = (c.tid >> 6) << (6 + Cfg::LOG_E);
-    const uint32_t lbase = Cfg::lds_index(wbase + (c.tid & 63u) * V);
+    size_t tile0;
+    uint32_t pg0, wbase, lbase, lane;
+    NTT_HD LinearGeom(const Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
+        tile0 = uniform_word<Cfg>(c, a, it);
+        pg0 = (c.pg_base + (uint32_t) it * (uint32_t) a.pg_stride) << a.log_up;
+        wbase = (c.tid >> 6) << (6 + Cfg::LOG_E);
+        lane = (c.tid & 63u) * V;
+        lbase = Cfg::lds_index(wbase + lane);
+    }
+    NTT_HD uint32_t lin(int i) const { return wbase + (uint32_t) i * STEP + lane; }
+    NTT_HD uint32_t lds(int i) const { return lbase + (uint32_t) i * (STEP + (STEP >> Cfg::LOG_E) * Cfg::VW); }
+    // unit of this chunk -> its polynomial (ragged batch tail)
+    NTT_HD bool active(const PassArgs<Cfg> &a, int i) const { return (pg0 | ((lin(i) >> Cfg::LOG_M) >> a.log_uh)) < a.batch; }
+};
+
+// Cache policy of the linear tile copies (aux bits: 2 = nt).  Measured same-process (tools/ab_latency.py): non-temporal is worth
+// -6.5 % on 4-byte words at N = 2^8, batch 2^20 and neutral on the other 4-byte shapes; on 8-byte words (N = 2^12, batch 16384)
+// it measured +1.5 %, so those keep the default policy.
+#ifndef NTT_AUX_LIN
+#define NTT_AUX_LIN(W) (sizeof(W) == 4 ? 2 : 0)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+// Descriptor over [base, end of the [batch][N] buffer): chunks of polynomials past the batch (ragged tail of a workgroup
+// that holds several polynomials) lie beyond it, so their loads return zero and their stores are dropped by the
+// hardware's range check -- no branch around any access, every load of a tile is issued back to back.
+template <class Cfg>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t linear_rsrc(const typename Cfg::W *buf, const PassArgs<Cfg> &a, size_t tile0) {
+    const uint64_t rem = (((uint64_t) a.batch << a.n) - (uint64_t) tile0) * sizeof(typename Cfg::W);  // > 0: the group exists
+    return __builtin_amdgcn_make_buffer_rsrc((void *) (buf + tile0), 0, rem > 0xFFFFFFFFull ? -1 : (int) (uint32_t) rem, 0x00020000);
+}
+using u32x4_t = unsigned int __attribute__((ext_vector_type(4)));
+#endif
+
+// HBM -> registers: ALL the tile's chunks of this thread are requested before anything waits on one of them (c.x is the
+// staging set: chunk i in x[i*V .. i*V+V)); with a fused pointwise product (a.in2, the negacyclic product's middle leg)
+// the second operand's chunks follow and the products replace the staged words.
+template <class Cfg>
+NTT_HD void phase_linear_issue(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
+    using G = LinearGeom<Cfg>;
+    using Ch = typename G::Ch;
+    const G g(c, a, it);
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(Ch) == 16, "linear tiles move 16-byte chunks");
+    const uint32_t voff = (g.wbase + g.lane) * (uint32_t) sizeof(typename Cfg::W);
+    const __amdgpu_buffer_rsrc_t rs = linear_rsrc<Cfg>(a.in, a, g.tile0);
 #pragma unroll
-    for (int i = 0; i < ITER; ++i) {
-        constexpr uint32_t STEP = 64 * V;  // multiple of E: pad term is linear in i
-        const uint32_t lin = wbase + (uint32_t) i * STEP + (c.tid & 63u) * V;
-        // unit of this chunk -> its polynomial (ragged batch tail)
-        const uint32_t u_p = (lin >> Cfg::LOG_M) >> a.log_uh;
-        const bool active = (pg0 | u_p) < a.batch;
-        const uint32_t l = lbase + (uint32_t) i * (STEP + (STEP >> Cfg::LOG_E) * Cfg::VW);
-        if constexpr (TO_LDS) {
-            Ch v;
-            if (active) {
-                v = *reinterpret_cast<const Ch *>(a.in + tile0 + lin);
-                if (a.in2 != nullptr) {  // fused pointwise product (negacyclic polymul's middle leg)
-                    const Ch w = *reinterpret_cast<const Ch *>(a.in2 + tile0 + lin);
+    for (int i = 0; i < G::ITER; ++i) {
+        const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (uint32_t) i * G::STEP * (uint32_t) sizeof(typename Cfg::W), NTT_AUX_LIN(typename Cfg::W));
+        Ch v;
+        __builtin_memcpy(&v, &d, 16);
 #pragma unroll
-                    for (int k = 0; k < V; ++k) v.v[k] = a.field.mul(a.field.mul(v.v[k], w.v[k]), a.pw_scale);
-                }
-            } else {
+        for (int k = 0; k < G::V; ++k) c.x[i * G::V + k] = v.v[k];
+    }
+    if (a.in2 != nullptr) {
+        const __amdgpu_buffer_rsrc_t rs2 = linear_rsrc<Cfg>(a.in2, a, g.tile0);
 #pragma unroll
-                for (int k = 0; k < V; ++k) v.v[k] = 0;
-            }
-            *reinterpret_cast<Ch *>(lds + l) = v;
-        } else {
-            if (active) *reinterpret_cast<Ch *>(a.out + tile0 + lin) = *reinterpret_cast<const Ch *>(lds + l);
+        for (int i = 0; i < G::ITER; ++i) {
+            const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(rs2, voff, (uint32_t) i * G::STEP * (uint32_t) sizeof(typename Cfg::W), NTT_AUX_LIN(typename Cfg::W));
+            Ch w;
+            __builtin_memcpy(&w, &d, 16);
+#pragma unroll
+            for (int k = 0; k < G::V; ++k) c.x[i * G::V + k] = a.field.mul(a.field.mul(c.x[i * G::V + k], w.v[k]), a.pw_scale);
         }
     }
+#else
+#pragma unroll
+    for (int i = 0; i < G::ITER; ++i) {
+        Ch v;
+#pragma unroll
+        for (int k = 0; k < G::V; ++k) v.v[k] = 0;
+        if (g.active(a, i)) v = *reinterpret_cast<const Ch *>(a.in + g.tile0 + g.lin(i));
+#pragma unroll
+        for (int k = 0; k < G::V; ++k) c.x[i * G::V + k] = v.v[k];
+    }
+    if (a.in2 != nullptr) {
+#pragma unroll
+        for (int i = 0; i < G::ITER; ++i) {
+            if (!g.active(a, i)) continue;
+            const Ch w = *reinterpret_cast<const Ch *>(a.in2 + g.tile0 + g.lin(i));
+#pragma unroll
+            for (int k = 0; k < G::V; ++k) c.x[i * G::V + k] = a.field.mul(a.field.mul(c.x[i * G::V + k], w.v[k]), a.pw_scale);
+        }
+    }
+#endif
+}
+
+// registers -> LDS (the wave's own segment of the tile)
+template <class Cfg>
+NTT_HD void phase_linear_commit(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *lds, int it) {
+    using G = LinearGeom<Cfg>;
+    using Ch = typename G::Ch;
+    const G g(c, a, it);
+#pragma unroll
+    for (int i = 0; i < G::ITER; ++i) {
+        Ch v;
+#pragma unroll
+        for (int k = 0; k < G::V; ++k) v.v[k] = c.x[i * G::V + k];
+        *reinterpret_cast<Ch *>(lds + g.lds(i)) = v;
+    }
+}
+
+// LDS -> HBM (the inverse CONTIG passes' last step)
+template <class Cfg>
+NTT_HD void phase_linear_store(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *lds, int it) {
+    using G = LinearGeom<Cfg>;
+    using Ch = typename G::Ch;
+    const G g(c, a, it);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t voff = (g.wbase + g.lane) * (uint32_t) sizeof(typename Cfg::W);
+    const __amdgpu_buffer_rsrc_t rs = linear_rsrc<Cfg>(a.out, a, g.tile0);
+#pragma unroll
+    for (int i = 0; i < G::ITER; ++i) {
+        const Ch v = *reinterpret_cast<const Ch *>(lds + g.lds(i));
+        u32x4_t d;
+        __builtin_memcpy(&d, &v, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, (uint32_t) i * G::STEP * (uint32_t) sizeof(typename Cfg::W), NTT_AUX_LIN(typename Cfg::W));
+    }
+#else
+#pragma unroll
+    for (int i = 0; i < G::ITER; ++i)
+        if (g.active(a, i)) *reinterpret_cast<Ch *>(a.out + g.tile0 + g.lin(i)) = *reinterpret_cast<const Ch *>(lds + g.lds(i));
+#endif
 }
 
 // ---- LDS-DMA prefetch (Cfg::DMA) ---------------------------------------------------------
@@ -782,14 +897,17 @@ NTT_HD void phase_canon(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
     }
 }
 
-NTT_HD void wave_prio(int level) {
+// raise the wave priority around a phase / drop it again; compiled in only for the phases NTT_SETPRIO selects
+template <int BIT>
+NTT_HD void prio_up() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (NTT_SETPRIO) {
-        if (level) __builtin_amdgcn_s_setprio(3);
-        else __builtin_amdgcn_s_setprio(0);
-    }
-#else
-    (void) level;
+    if constexpr ((NTT_SETPRIO & BIT) != 0) __builtin_amdgcn_s_setprio(3);
+#endif
+}
+template <int BIT>
+NTT_HD void prio_down() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr ((NTT_SETPRIO & BIT) != 0) __builtin_amdgcn_s_setprio(0);
 #endif
 }
 
@@ -808,10 +926,20 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     // and a register round, it is placed there (after the round) instead of at the end of the iteration: a wave
     // issues its next loads right behind its stores and computes a round while the others catch up.
     constexpr bool LATE_SYNC = NTT_LATE_SYNC && Cfg::DIRECT_LOAD && R > 1 && !Cfg::DMA && !Cfg::REG_PREFETCH;
-    ex.init(a);
+    // Tile staged linearly through LDS by ordinary loads (forward CONTIG passes without LDS-DMA: every 4-byte-word one, the
+    // Goldilocks radix-16 ones): the first tile's loads are issued BEFORE the resident twiddles are fetched, so that in a
+    // one-generation launch (BASELINE config 2: 1024 workgroups, all resident at once) the coefficient requests are the oldest
+    // in flight and the table reads overlap their latency instead of preceding it.
+    constexpr bool EARLY_LOAD = !Cfg::DIRECT_LOAD && !Cfg::DMA && !Cfg::REG_PREFETCH && !Cfg::CDMA;
+    if constexpr (EARLY_LOAD) ex.init_indices(a);
+    else ex.init(a);
     auto group_valid = [&](int it) {  // uniform: does polynomial group `it` of this workgroup exist
         return it < a.ppw && (((uint64_t) ex.pg_base() + (uint64_t) it * (uint32_t) a.pg_stride) << a.log_up) < a.batch;
     };
+    if constexpr (EARLY_LOAD) {
+        if (group_valid(0)) ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, 0); phase_linear_issue<Cfg>(c, a, 0); });
+        ex.each([&](C &c) { phase_init_twiddles<Cfg>(c, a); });
+    }
     if constexpr (Cfg::DMA) {
         if (group_valid(0)) ex.each([&](C &c) { phase_dma_issue<Cfg>(c, a, ex.lds(), 0); });
     }
@@ -841,9 +969,9 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.sync(std::false_type{});
             ex.each([&](C &c) { phase_lds_read<Cfg, 1>(c, tile); });
             ex.sync(std::false_type{});  // the tile is dead: the next one may land in it
-            wave_prio(NTT_SETPRIO & 1);
+            prio_up<1>();
             if (group_valid(it + 1)) ex.each([&](C &c) { phase_dma_issue_col<Cfg>(c, a, ex.lds(), it + 1); });
-            wave_prio(0);
+            prio_down<1>();
             ex.each([&](C &c) { phase_compute<Cfg, 1, M32_MODE>(c, a); });
             ex.each([&](C &c) { phase_canon<Cfg>(c, a); });
             ex.each([&](C &c) { phase_store_direct<Cfg, 1>(c, a, it); });
@@ -859,9 +987,9 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         if constexpr (Cfg::DMA) {
             if (it == 0) ex.each([&](C &) { phase_dma_wait<Cfg, true>(); });
             else ex.each([&](C &) { phase_dma_wait<Cfg, false>(); });
-            wave_prio(NTT_SETPRIO & 1);
+            prio_up<1>();
             if (group_valid(it + 1)) ex.each([&](C &c) { phase_dma_issue<Cfg>(c, a, ex.lds(), it + 1); });
-            wave_prio(0);
+            prio_down<1>();
             ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, tile); });
         } else if constexpr (Cfg::REG_PREFETCH) {
             ex.each([&](C &c) {
@@ -870,12 +998,15 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             });
             if (group_valid(it + 1)) ex.each([&](C &c) { phase_load_direct<Cfg, FIRST, true>(c, a, it + 1); });
         } else if constexpr (Cfg::DIRECT_LOAD) {
-            wave_prio(NTT_SETPRIO & 1);
+            prio_up<1>();
             ex.each([&](C &c) { phase_load_direct<Cfg, FIRST>(c, a, it); });
-            wave_prio(0);
+            prio_down<1>();
         } else {
-            ex.each([&](C &c) { phase_linear<Cfg, true>(c, a, tile, it); });
-            ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
+            if (it > 0) ex.each([&](C &c) { phase_linear_issue<Cfg>(c, a, it); });
+            ex.each([&](C &c) { phase_linear_commit<Cfg>(c, a, tile, it); });
+            // round 0 of thread t reads words [E*t, E*t + E) of the tile: the segment its own wave has just staged, so this
+            // hand-off is wave-local whatever the unit size (as with the LDS-DMA tiles); the later exchanges keep their barrier
+            ex.sync(std::true_type{});
             ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, tile); });
         }
         static_for<0, R>([&](auto kk) {
@@ -887,23 +1018,23 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
                 if constexpr (LATE_SYNC && k == 0) {
                     if (it > 0) ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});  // previous iteration's tile reads are done
                 }
-                wave_prio(NTT_SETPRIO & 4);
+                prio_up<4>();
                 ex.each([&](C &c) { phase_lds_write<Cfg, r>(c, tile); });
                 ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
                 ex.each([&](C &c) { phase_lds_read<Cfg, rn>(c, tile); });
-                if (NTT_SETPRIO & 4) wave_prio(0);
+                prio_down<4>();
             }
         });
         if constexpr (Cfg::INV) ex.each([&](C &c) { phase_scale<Cfg>(c, a); });
         ex.each([&](C &c) { phase_canon<Cfg>(c, a); });
         if constexpr (Cfg::DIRECT_STORE) {
-            wave_prio(NTT_SETPRIO & 2);
+            prio_up<2>();
             ex.each([&](C &c) { phase_store_direct<Cfg, LAST>(c, a, it); });
-            wave_prio(0);
+            prio_down<2>();
         } else {
             ex.each([&](C &c) { phase_lds_write<Cfg, LAST>(c, tile); });
-            ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
-            ex.each([&](C &c) { phase_linear<Cfg, false>(c, a, tile, it); });
+            ex.sync(std::true_type{});  // round 0's words of a wave's threads are that wave's segment of the linear copy
+            ex.each([&](C &c) { phase_linear_store<Cfg>(c, a, tile, it); });
         }
         ex.iter_done(it);  // fused schedule: publish the previous polynomial's tile
         ++completed;
@@ -1000,9 +1131,9 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
     // unit's product is transformed forward; the three data sets (working words, kept transform of a, prefetch) are
     // never live together, 2 x E words at any time.
     if (NTT_PRODUCT_PREFETCH_A && group_valid(0)) {
-        wave_prio(NTT_SETPRIO & 1);
+        prio_up<1>();
         ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *, W *pre) { phase_load_direct_to<CI, R - 1>(ci, aa, 0, pre, lane_active(ci, 0)); });
-        wave_prio(0);
+        prio_down<1>();
     }
     for (int it = 0; it < aa.ppw; ++it) {
         if (!group_valid(it)) break;
@@ -1017,9 +1148,9 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
                 phase_load_direct_to<CI, R - 1>(ci, aa, it, ci.x, ci.active);
             }
         });
-        wave_prio(NTT_SETPRIO & 1);
+        prio_up<1>();
         ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *, W *pre) { phase_load_direct_to<CI, R - 1>(ci, ab, it, pre, ci.active); });
-        wave_prio(0);
+        prio_down<1>();
         inverse_unit(aa, tile);
         ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *keep, W *pre) {
 #pragma unroll
@@ -1050,9 +1181,9 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
             for (int e = 0; e < CI::E; ++e) cf.x[e] = af.field.mul(af.field.mul(keep[e], ci.x[e]), af.pw_scale);
         });
         if (NTT_PRODUCT_PREFETCH_A && group_valid(it + 1)) {
-            wave_prio(NTT_SETPRIO & 1);
+            prio_up<1>();
             ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *, W *pre) { phase_load_direct_to<CI, R - 1>(ci, aa, it + 1, pre, lane_active(ci, it + 1)); });
-            wave_prio(0);
+            prio_down<1>();
         }
         // no barrier here: the forward rounds first WRITE the round-0 positions, which this thread itself read last
         static_for<0, R>([&](auto kk) {

@@ -28,6 +28,9 @@ struct EmuExec {
     void init(const PassArgs<Cfg> &a) {
         for (int t = 0; t < Cfg::NT; t++) phase_init<Cfg>(ctx[t], a, (uint32_t) t, bx, by);
     }
+    void init_indices(const PassArgs<Cfg> &a) {
+        for (int t = 0; t < Cfg::NT; t++) phase_init<Cfg, false>(ctx[t], a, (uint32_t) t, bx, by);
+    }
     // only_wave >= 0: step just that wave's 64 lanes (used to prove WAVE_LOCAL passes never read
     // another wave's LDS words: the four waves are then run one after the other, start to finish)
     int only_wave = -1;
