@@ -128,6 +128,16 @@ struct PassCfg {
     // the exchanges need no workgroup barrier (LDS operations of a wave execute in order) and the
     // four waves of a workgroup run fully decoupled.
     static constexpr bool WAVE_LOCAL = CONTIG && (LOG_M - LOG_E) <= 6;
+    // ... and in a wider unit the exchange between two rounds whose windows both start at bit 6 or below is wave-local
+    // all the same: thread q holds mid = (q >> b0) << (b0 + LOG_E) | e << b0 | (q & (2^b0 - 1)) in the round whose window
+    // starts at b0, so q's bits 6 and up -- the wave -- sit at mid bits 6 + LOG_E and up in EVERY round with b0 <= 6: the
+    // wave owns the same 64 * E words before and after.  A 12-stage radix-8 pass (windows 0, 3, 6, 9) keeps a workgroup
+    // barrier only for its last exchange.
+#if defined(NTT_EMU_FORCE_WAVE_LOCAL)  // tests only: a deliberately WRONG rule, to show that the host model's tracker catches it
+    static constexpr bool exchange_wave_local(int, int) { return CONTIG; }
+#else
+    static constexpr bool exchange_wave_local(int ra, int rb) { return CONTIG && win(ra) <= 6 && win(rb) <= 6; }
+#endif
     // Forward CONTIG radix-8 pass on 8-byte words: the tile of the NEXT polynomial is fetched
     // straight into a second LDS buffer by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no VALU)
     // while the current one is transformed, so no wave ever waits on HBM in steady state.  The
@@ -302,6 +312,24 @@ constexpr bool tw_uniform() {
     // so the table entries live in SGPRs (column passes of 8 stages, CONTIG passes of 12)
     return Cfg::LOG_U == 0 && (Cfg::win(r) + Cfg::LOG_E >= Cfg::LOG_M) && sizeof(typename Cfg::W) == 8;
 }
+
+// ---- host index model only: LDS hazard tracking -----------------------------------------
+// tests/emu defines NTT_EMU_TRACK and points `lds_track` at a tracker: every LDS word access of the phases below is then
+// reported with the accessing wave, and the tracker asserts that no wave reads or overwrites a word another wave wrote
+// or read since the last WORKGROUP barrier -- i.e. that every sync() the schedule declares wave-local really is.
+#if defined(NTT_EMU_TRACK) && !defined(__HIP_DEVICE_COMPILE__)
+struct LdsTrack {
+    virtual void access(const void *word, uint32_t tid, bool write) = 0;
+    virtual ~LdsTrack() {}
+};
+inline LdsTrack *&lds_track() {
+    static thread_local LdsTrack *t = nullptr;
+    return t;
+}
+#define NTT_LDS_ACCESS(ptr, tid, wr) do { if (::ntt::lds_track()) ::ntt::lds_track()->access((ptr), (tid), (wr)); } while (0)
+#else
+#define NTT_LDS_ACCESS(ptr, tid, wr) do { } while (0)
+#endif
 
 // ---- phases -------------------------------------------------------------------
 template <class W, int V>
@@ -647,6 +675,7 @@ NTT_HD void phase_linear_commit(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cf
         Ch v;
 #pragma unroll
         for (int k = 0; k < G::V; ++k) v.v[k] = c.x[i * G::V + k];
+        for (int k = 0; k < G::V; ++k) NTT_LDS_ACCESS(lds + g.lds(i) + k, c.tid, true);
         *reinterpret_cast<Ch *>(lds + g.lds(i)) = v;
     }
 }
@@ -669,8 +698,10 @@ NTT_HD void phase_linear_store(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg
     }
 #else
 #pragma unroll
-    for (int i = 0; i < G::ITER; ++i)
+    for (int i = 0; i < G::ITER; ++i) {
+        for (int k = 0; k < G::V; ++k) NTT_LDS_ACCESS(lds + g.lds(i) + k, c.tid, false);
         if (g.active(a, i)) *reinterpret_cast<Ch *>(a.out + g.tile0 + g.lin(i)) = *reinterpret_cast<const Ch *>(lds + g.lds(i));
+    }
 #endif
 }
 
@@ -705,7 +736,10 @@ NTT_HD void phase_dma_issue(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W
 #else
     for (int i = 0; i < ITER; ++i) {
         const uint32_t lin = wbase + (uint32_t) i * 64 * V + (c.tid & 63u) * V;
-        for (int k = 0; k < V; ++k) lds[buf + lin + k] = a.in[tile0 + lin + k];
+        for (int k = 0; k < V; ++k) {
+            NTT_LDS_ACCESS(lds + buf + lin + k, c.tid, true);
+            lds[buf + lin + k] = a.in[tile0 + lin + k];
+        }
     }
 #endif
 }
@@ -745,14 +779,20 @@ template <class Cfg, int r>
 NTT_HD void phase_lds_read(Ctx<Cfg> &c, const typename Cfg::W *lds) {
     const typename Cfg::W *p = lds + c.lds_base[r];
 #pragma unroll
-    for (int e = 0; e < Cfg::E; ++e) c.x[e] = p[lds_elem_off<Cfg>(r, e)];
+    for (int e = 0; e < Cfg::E; ++e) {
+        NTT_LDS_ACCESS(p + lds_elem_off<Cfg>(r, e), c.tid, false);
+        c.x[e] = p[lds_elem_off<Cfg>(r, e)];
+    }
 }
 
 template <class Cfg, int r>
 NTT_HD void phase_lds_write(Ctx<Cfg> &c, typename Cfg::W *lds) {
     typename Cfg::W *p = lds + c.lds_base[r];
 #pragma unroll
-    for (int e = 0; e < Cfg::E; ++e) p[lds_elem_off<Cfg>(r, e)] = c.x[e];
+    for (int e = 0; e < Cfg::E; ++e) {
+        NTT_LDS_ACCESS(p + lds_elem_off<Cfg>(r, e), c.tid, true);
+        p[lds_elem_off<Cfg>(r, e)] = c.x[e];
+    }
 }
 
 // The butterflies of round r (src/aie_core.cc:104-125 ntt_stage_parallel8;
@@ -929,8 +969,10 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     // Tile staged linearly through LDS by ordinary loads (forward CONTIG passes without LDS-DMA: every 4-byte-word one, the
     // Goldilocks radix-16 ones): the first tile's loads are issued BEFORE the resident twiddles are fetched, so that in a
     // one-generation launch (BASELINE config 2: 1024 workgroups, all resident at once) the coefficient requests are the oldest
-    // in flight and the table reads overlap their latency instead of preceding it.
-    constexpr bool EARLY_LOAD = !Cfg::DIRECT_LOAD && !Cfg::DMA && !Cfg::REG_PREFETCH && !Cfg::CDMA;
+    // in flight and the table reads overlap their latency instead of preceding it.  (The same reordering for the kernels
+    // that load straight into the round registers measured neutral to +3 % on 4-byte words and costs the 8-byte column
+    // pass 2 VGPRs beyond 128: not done.)  Exec::early_ok = false (tools-side fused schedule) keeps the old order.
+    constexpr bool EARLY_LOAD = Exec::early_ok && !Cfg::DIRECT_LOAD && !Cfg::DMA && !Cfg::REG_PREFETCH && !Cfg::CDMA;
     if constexpr (EARLY_LOAD) ex.init_indices(a);
     else ex.init(a);
     auto group_valid = [&](int it) {  // uniform: does polynomial group `it` of this workgroup exist
@@ -1002,7 +1044,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.each([&](C &c) { phase_load_direct<Cfg, FIRST>(c, a, it); });
             prio_down<1>();
         } else {
-            if (it > 0) ex.each([&](C &c) { phase_linear_issue<Cfg>(c, a, it); });
+            if (!EARLY_LOAD || it > 0) ex.each([&](C &c) { phase_linear_issue<Cfg>(c, a, it); });
             ex.each([&](C &c) { phase_linear_commit<Cfg>(c, a, tile, it); });
             // round 0 of thread t reads words [E*t, E*t + E) of the tile: the segment its own wave has just staged, so this
             // hand-off is wave-local whatever the unit size (as with the LDS-DMA tiles); the later exchanges keep their barrier
@@ -1020,7 +1062,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
                 }
                 prio_up<4>();
                 ex.each([&](C &c) { phase_lds_write<Cfg, r>(c, tile); });
-                ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});
+                ex.sync(std::integral_constant<bool, Cfg::exchange_wave_local(r, rn)>{});
                 ex.each([&](C &c) { phase_lds_read<Cfg, rn>(c, tile); });
                 prio_down<4>();
             }
@@ -1122,7 +1164,7 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
                 ex.eachI([&](Ctx<CI> &c) { phase_lds_write<CI, r>(c, tile); });
                 // the next round's twiddles are requested from the LDS table before the barrier: their latency overlaps the wait
                 if constexpr (NTT_PRODUCT_TW_EARLY && !CI::preload(r - 1)) ex.eachI([&](Ctx<CI> &c) { tw_table_read<CI, r - 1>(c, ex.tabI()); });
-                ex.sync(WL{});
+                ex.sync(std::integral_constant<bool, CI::exchange_wave_local(r, r - 1)>{});
                 ex.eachI([&](Ctx<CI> &c) { phase_lds_read<CI, r - 1>(c, tile); });
             }
         });
@@ -1194,7 +1236,7 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
             if constexpr (r < R - 1) {
                 ex.eachF([&](Ctx<CF> &c) { phase_lds_write<CF, r>(c, tile); });
                 if constexpr (NTT_PRODUCT_TW_EARLY && !CF::preload(r + 1)) ex.eachF([&](Ctx<CF> &c) { tw_table_read<CF, r + 1>(c, ex.tabF()); });
-                ex.sync(WL{});
+                ex.sync(std::integral_constant<bool, CF::exchange_wave_local(r, r + 1)>{});
                 ex.eachF([&](Ctx<CF> &c) { phase_lds_read<CF, r + 1>(c, tile); });
             }
         });

@@ -11,6 +11,10 @@
 
 #include <vector>
 
+#define NTT_EMU_TRACK 1
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "../../ntt_aie_amd/csrc/pass.h"
 #include "../../ntt_aie_amd/csrc/plan.h"
 
@@ -19,8 +23,53 @@ using namespace ntt::host;
 
 namespace {
 
+// LDS hazard tracker (pass.h: NTT_LDS_ACCESS).  epoch = number of WORKGROUP barriers so far.  A word may be read by a wave
+// only if its last write is this wave's own or older than the last barrier; it may be written only if, in addition, every
+// read of it since the last barrier was this wave's own.  Wave-local syncs do not advance the epoch: LDS operations of one
+// wave execute in order, so same-wave accesses are always fine.  A violation aborts the process (the test then fails).
+struct EmuLdsTrack : ntt::LdsTrack {
+    struct St {
+        int w_wave = -1, w_epoch = -1, r_wave = -1, r_epoch = -1;  // r_wave -2: several waves read it in r_epoch
+    };
+    std::vector<St> st;
+    const char *base = nullptr;
+    size_t word_bytes = 1;
+    int epoch = 0;
+    const char *what = "";
+    void reset(const void *tile, size_t words, size_t wb) {  // a new workgroup
+        base = (const char *) tile;
+        word_bytes = wb;
+        st.assign(words, St());
+        epoch = 0;
+    }
+    void barrier() { ++epoch; }
+    void access(const void *word, uint32_t tid, bool write) override {
+        const int wave = (int) (tid >> 6);
+        const size_t idx = (size_t) ((const char *) word - base) / word_bytes;
+        if ((const char *) word < base || idx >= st.size()) return;  // not the tile (the product pass's twiddle tables)
+        St &s = st[idx];
+        const bool raw = s.w_epoch == epoch && s.w_wave != wave && s.w_wave != -1;
+        const bool war = write && s.r_epoch == epoch && s.r_wave != wave && s.r_wave != -1;
+        if (raw || war) {
+            fprintf(stderr, "LDS hazard in %s: wave %d %s a word that wave %d %s since the last workgroup barrier (epoch %d)\n", what, wave,
+                    write ? "writes" : "reads", raw ? s.w_wave : s.r_wave, raw ? "wrote" : "read", epoch);
+            abort();
+        }
+        if (write) {
+            s.w_wave = wave;
+            s.w_epoch = epoch;
+        } else if (s.r_epoch == epoch && s.r_wave != wave) {
+            s.r_wave = -2;
+        } else {
+            s.r_wave = wave;
+            s.r_epoch = epoch;
+        }
+    }
+};
+
 template <class Cfg>
 struct EmuExec {
+    static constexpr bool early_ok = true;
     std::vector<Ctx<Cfg>> ctx;
     std::vector<typename Cfg::W> tile;
     uint32_t bx, by;
@@ -39,8 +88,9 @@ struct EmuExec {
         const int lo = only_wave < 0 ? 0 : 64 * only_wave, hi = only_wave < 0 ? Cfg::NT : lo + 64;
         for (int t = lo; t < hi; t++) f(ctx[t]);
     }
-    template <class B>
-    void sync(B) {}
+    EmuLdsTrack tr;
+    void sync(std::false_type) { tr.barrier(); }
+    void sync(std::true_type) {}
     uint32_t pg_base() const { return ctx[0].pg_base; }
     bool iter_begin(int) { return true; }
     void iter_done(int) {}
@@ -74,8 +124,9 @@ struct EmuProductExec {
     void eachF(Fn &&f) { for (int t = lo(); t < hi(); t++) f(cf[t]); }
     template <class Fn>
     void eachIF(Fn &&f) { for (int t = lo(); t < hi(); t++) f(ci[t], cf[t], &keep[(size_t) t * CI::E], &pre[(size_t) t * CI::E]); }
-    template <class B>
-    void sync(B) {}
+    EmuLdsTrack tr;
+    void sync(std::false_type) { tr.barrier(); }
+    void sync(std::true_type) {}
     uint32_t pg_base() const { return ci[0].pg_base; }
     W *lds() { return tile.data(); }
     W *tabI() { return tab_i.data(); }
@@ -150,7 +201,11 @@ int run_product_mid(int n, uint32_t batch, uint32_t target_wgs, const void *a_in
             ex.bx = bx;
             ex.by = by;
             memset(ex.tile.data(), 0xA5, ex.tile.size() * sizeof(W));
+            ex.tr.reset(ex.tile.data(), ex.tile.size(), sizeof(W));
+            ex.tr.what = "product pass";
+            ntt::lds_track() = &ex.tr;
             run_product_pass<CI, CF>(ex, aa, ab, af);
+            ntt::lds_track() = nullptr;
         }
     return 0;
 }
@@ -187,6 +242,9 @@ int run_cfg(const Erased &e) {
             ex.by = by;
             // poison the tile: a read of a word nobody wrote this launch shows up as garbage
             memset(ex.tile.data(), 0xA5, ex.tile.size() * sizeof(W));
+            ex.tr.reset(ex.tile.data(), ex.tile.size(), sizeof(W));
+            ex.tr.what = Cfg::CONTIG ? "CONTIG pass" : "column pass";
+            ntt::lds_track() = &ex.tr;
             if constexpr (Cfg::WAVE_LOCAL) {
                 for (int w = 0; w < Cfg::NT / 64; w++) {
                     ex.only_wave = w;
@@ -196,6 +254,7 @@ int run_cfg(const Erased &e) {
             } else {
                 run_pass<Cfg>(ex, a);
             }
+            ntt::lds_track() = nullptr;
         }
     return 0;
 }

@@ -169,3 +169,30 @@ def test_composite_odd_modulus(oracle):
     assert L.emu_transform(4, 6, p, T.ctypes.data, a.ctypes.data, out.ctypes.data, 1, 0, 0, 1, 2048, 0) == 0
     assert np.array_equal(out, oracle.ntt(a, T, p))
     assert L.emu_transform(4, 6, p, T.ctypes.data, a.ctypes.data, out.ctypes.data, 1, 1, 0, 1, 2048, 0) == -5
+
+
+def test_lds_hazard_tracker_catches_a_wrong_wave_local_rule(tmp_path):
+    """The host model tracks every LDS word access (pass.h: NTT_LDS_ACCESS) and aborts when a wave touches a word that
+    another wave wrote or read since the last WORKGROUP barrier.  All the tests above run under it, which is what proves
+    that the exchanges the schedule declares wave-local (PassCfg::exchange_wave_local, the first hand-off of a linearly
+    staged tile) really are.  Here the same model is built with a deliberately wrong rule -- every CONTIG exchange declared
+    wave-local -- and must abort on a 12-stage unit, whose last exchange crosses waves."""
+    import subprocess
+    import sys
+    import textwrap
+
+    so = tmp_path / "libntt_emu_wrong.so"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-DNTT_EMU_FORCE_WAVE_LOCAL", emu_lib.SRC, "-o", str(so)])
+    prog = textwrap.dedent("""
+        import ctypes as C, sys
+        import numpy as np
+        L = C.CDLL(sys.argv[1])
+        L.emu_transform.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint64]
+        n = 1 << 12
+        T = np.ones(n, dtype=np.uint32); a = np.arange(n, dtype=np.uint32).reshape(1, n); out = np.zeros_like(a)
+        L.emu_transform(4, 12, 3221225473, T.ctypes.data, a.ctypes.data, out.ctypes.data, 1, 0, 0, 1, 2048, 0)
+        print("no hazard reported")
+    """)
+    r = subprocess.run([sys.executable, "-c", prog, str(so)], capture_output=True, text=True)
+    assert r.returncode != 0 and "LDS hazard" in r.stderr, (r.returncode, r.stdout, r.stderr[-500:])

@@ -53,6 +53,7 @@ constexpr int TILE_LDS_WORDS = 2 * CfgA::TILE_WORDS > CfgB::LDS_WORDS ? 2 * CfgA
 template <class Cfg, bool PRODUCER>
 struct FusedExec {
     using W = typename Cfg::W;
+    static constexpr bool early_ok = false;  // a consumer may not load before iter_begin() has seen the producer's flag
     Ctx<Cfg> ctx;
     W *tile;
     uint32_t *flag;  // one LDS word behind the tile
