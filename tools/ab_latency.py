@@ -4,7 +4,7 @@ ntt_forward (or ntt_inverse), K launches back to back between two events on the 
 by round; every variant's output is compared word for word with the first one's.
 
 usage: ab_latency.py [--logn 12] [--p 3221225473] [--g 5] [--word-bytes 4] [--batch 1024] [--rounds 9] [--k 50] [--inverse]
-                     NAME=path ...
+                     [--no-check] NAME=path[+ENV=VAL...] ...
   e.g. ab_latency.py base=ab/libntt_base.so new=ntt_aie_amd/libntt_hip.so"""
 import argparse
 import ctypes as C
@@ -27,6 +27,7 @@ ap.add_argument("--batch", type=int, default=1024)
 ap.add_argument("--rounds", type=int, default=9)
 ap.add_argument("--k", type=int, default=50)
 ap.add_argument("--inverse", action="store_true")
+ap.add_argument("--no-check", action="store_true", help="timing experiments whose outputs are meaningless (NTT_DEBUG_FLAGS)")
 ap.add_argument("variants", nargs="+")
 args = ap.parse_args()
 
@@ -40,11 +41,21 @@ else:
 stream = torch.cuda.current_stream()
 plans = []
 for v in args.variants:
-    name, path = v.split("=", 1)
-    path = path if os.path.isabs(path) else os.path.join(ROOT, path)
+    name, rest = v.split("=", 1)
+    parts = rest.split("+")  # path[+ENV=VAL...]: set while this variant's plan is created (experiment builds read knobs there)
+    path = parts[0] if os.path.isabs(parts[0]) else os.path.join(ROOT, parts[0])
+    env = dict(q.split("=", 1) for q in parts[1:])
     L = _lib.open_library(path)
     h = C.c_void_p()
-    assert L.ntt_plan_create(C.byref(h), args.logn, args.p, args.word_bytes, 0) == 0, name
+    old_env = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    rc = L.ntt_plan_create(C.byref(h), args.logn, args.p, args.word_bytes, 0)
+    for k, o in old_env.items():
+        if o is None:
+            del os.environ[k]
+        else:
+            os.environ[k] = o
+    assert rc == 0, name
     assert L.ntt_plan_generate_twiddles(h, 0, args.g) == 0, name
     plans.append((name, L, h, torch.empty_like(x)))
 
@@ -72,14 +83,14 @@ for name, L, h, y in plans:
         launch(L, h, y)
 torch.cuda.synchronize()
 ref = plans[0][3]
-for name, L, h, y in plans[1:]:
-    assert torch.equal(y, ref), "variant %s differs from %s" % (name, plans[0][0])
+same = all(torch.equal(y, ref) for _, _, _, y in plans[1:])
+assert same or args.no_check, "a variant's output differs from %s's" % plans[0][0]
 samples = {name: [] for name, _, _, _ in plans}
 for r in range(args.rounds):
     for name, L, h, y in plans:
         samples[name].append(timed(L, h, y))
-print("logn=%d p=%d word_bytes=%d batch=%d %s: us per launch (%d launches back to back, %d interleaved rounds); outputs identical" % (
-    args.logn, args.p, args.word_bytes, args.batch, "inverse" if args.inverse else "forward", args.k, args.rounds))
+print("logn=%d p=%d word_bytes=%d batch=%d %s: us per launch (%d launches back to back, %d interleaved rounds); outputs %s" % (
+    args.logn, args.p, args.word_bytes, args.batch, "inverse" if args.inverse else "forward", args.k, args.rounds, "identical" if same else "DIFFER (--no-check)"))
 for name, _, _, _ in plans:
     s = samples[name]
     print("  %-12s median %8.3f  min %8.3f" % (name, statistics.median(s), min(s)), flush=True)
