@@ -223,6 +223,15 @@ using ColPassCfg = std::conditional_t<
     PassCfg<F, LOG_M, 4, false, INV, 0xF, 3, 9>,
     PassCfg<F, LOG_M, col_log_c(sizeof(typename F::W)), false, INV, 0xF, 4, col_log_nt(sizeof(typename F::W))>>;
 
+// How the rows of blockIdx.y share the polynomial groups of the batch.  Rows [0, rows[0]) stream `ppw` groups each through
+// their resident twiddles; the next rows[1] rows ppw/2 each, then ppw/4, then ppw/8 (0 rows = level absent).  Rows are
+// dispatched in ascending order, so the launch ends with short workgroups: the drain of a launch -- slots idling while the
+// last long workgroups finish, which the next (dependent) launch cannot fill -- shrinks with them, while most of the batch
+// still amortises its twiddle loads over `ppw` polynomials (pass_geometry() decides; {grid_y, 0, 0, 0} = no taper).
+struct Taper {
+    uint32_t rows[4];
+};
+
 template <class Cfg>
 struct PassArgs {
     using W = typename Cfg::W;
@@ -233,7 +242,8 @@ struct PassArgs {
     int n;   // log2 N
     int s0;  // first stage of the pass
     uint32_t batch;
-    int ppw;     // polynomials streamed per workgroup along blockIdx.y
+    int ppw;     // polynomials streamed per workgroup along blockIdx.y (rows of the first taper level)
+    Taper tp;
     int log_ul;  // unit split: lo-tiles, hi values, polynomials (sum = LOG_U)
     int log_uh;
     int log_up;
@@ -256,7 +266,8 @@ struct Ctx {
     W xn[Cfg::REG_PREFETCH ? Cfg::E : 1];  // prefetched words of the next iteration
     W tw[Cfg::R][Cfg::E > 1 ? Cfg::E - 1 : 1];
     uint32_t tid, bx, by;
-    uint32_t pg_base;        // first polynomial group of this workgroup (by * ppw for the plain launches)
+    uint32_t pg_base;        // first polynomial group of this workgroup
+    int ppw;                 // ... and how many it streams (PassArgs::ppw halved once per taper level)
     uint32_t q, hi;          // mid-thread index, hi value (twiddle addressing)
     uint32_t up;             // polynomial sub-index inside the workgroup
     uint32_t lane_ld, lane_st;       // lane part of the global word index (first / last round)
@@ -393,7 +404,19 @@ NTT_HD void phase_init(Ctx<Cfg> &c, const PassArgs<Cfg> &a, uint32_t tid, uint32
     c.tid = tid;
     c.bx = bx;
     c.by = by;
-    c.pg_base = by * (uint32_t) a.ppw;
+    {
+        uint32_t y = by, base = 0;
+        int p = a.ppw;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (y < a.tp.rows[k]) break;
+            base += a.tp.rows[k] * (uint32_t) p;
+            y -= a.tp.rows[k];
+            p >>= 1;
+        }
+        c.pg_base = base + y * (uint32_t) p;
+        c.ppw = p;
+    }
     const uint32_t col = tid & (Cfg::C - 1);
     c.q = (tid >> Cfg::LOG_C) & ((1u << Cfg::LOG_Q) - 1u);
     const uint32_t u = Cfg::LOG_U == 0 ? 0u : (tid >> (Cfg::LOG_C + Cfg::LOG_Q));
@@ -976,7 +999,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     if constexpr (EARLY_LOAD) ex.init_indices(a);
     else ex.init(a);
     auto group_valid = [&](int it) {  // uniform: does polynomial group `it` of this workgroup exist
-        return it < a.ppw && (((uint64_t) ex.pg_base() + (uint64_t) it * (uint32_t) a.pg_stride) << a.log_up) < a.batch;
+        return it < ex.ppw() && (((uint64_t) ex.pg_base() + (uint64_t) it * (uint32_t) a.pg_stride) << a.log_up) < a.batch;
     };
     if constexpr (EARLY_LOAD) {
         if (group_valid(0)) ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, 0); phase_linear_issue<Cfg>(c, a, 0); });
@@ -993,7 +1016,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         // barrier [issue the NEXT tile's DMA into the same buffer] compute round 1, store.
         static_assert(R == 2 && Cfg::LOG_U == 0 && !Cfg::INV, "8-stage forward column pass");
         if (group_valid(0)) ex.each([&](C &c) { phase_dma_issue_col<Cfg>(c, a, ex.lds(), 0); });
-        for (int it = 0; it < a.ppw; ++it) {
+        for (int it = 0; it < ex.ppw(); ++it) {
             if (!group_valid(it)) break;
             ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, it); });
             typename Cfg::W *const tile = ex.lds();
@@ -1021,7 +1044,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         return;
     }
     int completed = 0;
-    for (int it = 0; it < a.ppw; ++it) {
+    for (int it = 0; it < ex.ppw(); ++it) {
         if (!group_valid(it)) break;
         if (!ex.iter_begin(it)) break;  // fused schedule: wait for the producer of this polynomial (uniform)
         ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, it); });
@@ -1149,7 +1172,7 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
     });
     ex.sync(std::false_type{});
     auto group_valid = [&](int it) {
-        return it < aa.ppw && (((uint64_t) ex.pg_base() + (uint64_t) it) << aa.log_up) < aa.batch;
+        return it < ex.ppw() && (((uint64_t) ex.pg_base() + (uint64_t) it) << aa.log_up) < aa.batch;
     };
     auto lane_active = [&](const Ctx<CI> &c, int it) {  // does this lane's polynomial of iteration `it` exist
         return CI::LOG_U == 0 ? true : ((((c.pg_base + (uint32_t) it) << aa.log_up) | c.up) < aa.batch);
@@ -1177,7 +1200,7 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
         ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *, W *pre) { phase_load_direct_to<CI, R - 1>(ci, aa, 0, pre, lane_active(ci, 0)); });
         prio_down<1>();
     }
-    for (int it = 0; it < aa.ppw; ++it) {
+    for (int it = 0; it < ex.ppw(); ++it) {
         if (!group_valid(it)) break;
         W *const tile = ex.lds();
         ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &cf, W *, W *pre) {
@@ -1275,7 +1298,41 @@ struct PassGeom {
     int log_ul, log_uh, log_up;
     uint32_t grid_x, grid_y;
     int ppw;
+    Taper tp;
 };
+
+#ifndef NTT_TAPER
+#define NTT_TAPER 1  // 0: every row streams ppw groups (experiment knob)
+#endif
+#ifndef NTT_TAPER_SHIFT
+#define NTT_TAPER_SHIFT 2  // the last 2^-SHIFT of the polynomial groups is tapered
+#endif
+#ifndef NTT_TAPER_MIN
+#define NTT_TAPER_MIN 1  // fewest groups a tapered row streams
+#endif
+// Taper (see struct Taper): the last quarter of the polynomial groups goes to rows of ppw/2 (half of it), ppw/4 (a quarter)
+// and ppw/8 (the rest) groups, when the launch is long enough for its drain to matter (at least `min_wgs` workgroups
+// untapered) and the tapered grid still fits blockIdx.y.
+inline void taper_rows(PassGeom &g, uint64_t poly_groups, uint32_t min_wgs) {
+    const uint64_t P = (uint64_t) g.ppw;
+    g.tp = Taper{{g.grid_y, 0, 0, 0}};
+    if (!NTT_TAPER || P < 2 * NTT_TAPER_MIN || (uint64_t) g.grid_x * g.grid_y < min_wgs) return;
+    uint64_t rows[4] = {0, 0, 0, 0};
+    const uint64_t full = (poly_groups - (poly_groups >> NTT_TAPER_SHIFT)) / P * P;
+    rows[0] = full / P;
+    uint64_t rem = poly_groups - full;
+    for (int k = 1; k < 4 && rem > 0; ++k) {
+        const uint64_t p = P >> k;
+        const bool last = k == 3 || (p >> 1) < NTT_TAPER_MIN;
+        const uint64_t take = last ? rem : rem / 2 / p * p;
+        rows[k] = (take + p - 1) / p;
+        rem -= last ? rem : take;
+    }
+    const uint64_t gy = rows[0] + rows[1] + rows[2] + rows[3];
+    if (gy > 65535u) return;
+    g.tp = Taper{{(uint32_t) rows[0], (uint32_t) rows[1], (uint32_t) rows[2], (uint32_t) rows[3]}};
+    g.grid_y = (uint32_t) gy;
+}
 
 // n = log2 N, pass covers stages [s0, s0 + log_m); log_c columns; log_u units per WG
 inline PassGeom pass_geometry(int n, int s0, int log_m, int log_c, int log_u, bool contig,
@@ -1296,6 +1353,8 @@ inline PassGeom pass_geometry(int n, int s0, int log_m, int log_c, int log_u, bo
     g.ppw = (int) ppw;
     uint64_t gy = (poly_groups + ppw - 1) / ppw;
     g.grid_y = (uint32_t) gy;
+    g.tp = Taper{{g.grid_y, 0, 0, 0}};
+    if (gy <= 65535u) taper_rows(g, poly_groups, 2 * target_wgs > 4096 ? 4096 : 2 * target_wgs);
     return g;
 }
 

@@ -92,6 +92,7 @@ struct EmuExec {
     void sync(std::false_type) { tr.barrier(); }
     void sync(std::true_type) {}
     uint32_t pg_base() const { return ctx[0].pg_base; }
+    int ppw() const { return ctx[0].ppw; }
     bool iter_begin(int) { return true; }
     void iter_done(int) {}
     void pass_done(int) {}
@@ -128,6 +129,7 @@ struct EmuProductExec {
     void sync(std::false_type) { tr.barrier(); }
     void sync(std::true_type) {}
     uint32_t pg_base() const { return ci[0].pg_base; }
+    int ppw() const { return ci[0].ppw; }
     W *lds() { return tile.data(); }
     W *tabI() { return tab_i.data(); }
     W *tabF() { return tab_f.data(); }
@@ -176,6 +178,7 @@ int run_product_mid(int n, uint32_t batch, uint32_t target_wgs, const void *a_in
     aa.n = n;
     aa.batch = batch;
     aa.ppw = g.ppw;
+    aa.tp = g.tp;
     aa.log_ul = g.log_ul;
     aa.log_uh = g.log_uh;
     aa.log_up = g.log_up;
@@ -190,6 +193,7 @@ int run_product_mid(int n, uint32_t batch, uint32_t target_wgs, const void *a_in
     af.n = n;
     af.batch = batch;
     af.ppw = g.ppw;
+    af.tp = g.tp;
     af.log_ul = g.log_ul;
     af.log_uh = g.log_uh;
     af.log_up = g.log_up;
@@ -232,6 +236,7 @@ int run_cfg(const Erased &e) {
     a.skip_if = nullptr;
     PassGeom g = pass_geometry(e.n, e.s0, Cfg::LOG_M, Cfg::LOG_C, Cfg::LOG_U, Cfg::CONTIG, e.batch, e.target_wgs, Cfg::PPW_CAP);
     a.ppw = g.ppw;
+    a.tp = g.tp;
     a.log_ul = g.log_ul;
     a.log_uh = g.log_uh;
     a.log_up = g.log_up;
@@ -496,6 +501,32 @@ int emu_plan(int logn, int word_bytes, int *out_triples) {
         out_triples[3 * i + 2] = v[i].log_m;
     }
     return (int) v.size();
+}
+
+// the launch geometry of one pass, for tests: out = {ppw, grid_x, grid_y, log_up, rows[0..3]}; returns the number of
+// polynomial groups that the rule of phase_init() (the Ctx it fills for row by) covers other than exactly once
+int emu_geometry(int n, int s0, int log_m, int log_c, int log_u, int contig, uint64_t batch, uint32_t target_wgs, int ppw_cap, uint32_t *out) {
+    PassGeom g = pass_geometry(n, s0, log_m, log_c, log_u, contig != 0, batch, target_wgs, ppw_cap);
+    out[0] = (uint32_t) g.ppw; out[1] = g.grid_x; out[2] = g.grid_y; out[3] = (uint32_t) g.log_up;
+    for (int k = 0; k < 4; k++) out[4 + k] = g.tp.rows[k];
+    using Cfg = PassCfg<FieldM32, 1, 0, true, false>;  // the row rule does not depend on the configuration
+    PassArgs<Cfg> a;
+    memset((void *) &a, 0, sizeof(a));
+    a.ppw = g.ppw;
+    a.tp = g.tp;
+    a.n = n;
+    const uint64_t groups = (batch + (1ull << g.log_up) - 1) >> g.log_up;
+    std::vector<uint8_t> cov(groups, 0);
+    for (uint32_t by = 0; by < g.grid_y; by++) {
+        Ctx<Cfg> c;
+        phase_init<Cfg, false>(c, a, 0, 0, by);
+        if (c.ppw < 1) return -1;
+        for (int it = 0; it < c.ppw; it++)
+            if ((uint64_t) c.pg_base + it < groups && cov[(uint64_t) c.pg_base + it] < 255) cov[(uint64_t) c.pg_base + it]++;
+    }
+    int bad = 0;
+    for (uint64_t i = 0; i < groups; i++) bad += cov[i] != 1;
+    return bad;
 }
 
 // field arithmetic spot checks

@@ -24,6 +24,7 @@ def lib():
                                           C.c_uint32, C.c_uint64, C.c_uint32]
         L.emu_polymul_fused.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
         L.emu_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.emu_geometry.argtypes = [C.c_int] * 6 + [C.c_uint64, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
         for n in ("emu_gl_mul", "emu_gl_add", "emu_gl_sub"):
             getattr(L, n).restype = C.c_uint64
             getattr(L, n).argtypes = [C.c_uint64, C.c_uint64]

@@ -196,3 +196,22 @@ def test_lds_hazard_tracker_catches_a_wrong_wave_local_rule(tmp_path):
     """)
     r = subprocess.run([sys.executable, "-c", prog, str(so)], capture_output=True, text=True)
     assert r.returncode != 0 and "LDS hazard" in r.stderr, (r.returncode, r.stdout, r.stderr[-500:])
+
+
+def test_tapered_rows_cover_every_polynomial_group_once():
+    """pass_geometry() ends a long launch with rows that stream ppw/2, ppw/4, ppw/8 polynomial groups (struct Taper): the
+    row -> (first group, count) rule of phase_init() must cover every group exactly once, for ragged batches, every cap on
+    ppw, several polynomials per workgroup, and the headline shape must actually be tapered."""
+    L = emu_lib.lib()
+    out = (C.c_uint32 * 8)()
+    for batch in (1, 7, 512, 4095, 4096, 4097, 8192, 65536, 1000003):
+        for cap in (1, 2, 4, 8, 64):
+            for log_u in (0, 3, 5):
+                for target in (8, 8192):
+                    assert L.emu_geometry(16, 0, 8, 0, log_u, 1, batch, target, cap, out) == 0, (batch, cap, log_u, target, list(out))
+                    assert sum(out[4:8]) == out[2]
+    assert L.emu_geometry(16, 0, 8, 0, 3, 1, 4096, 8192, 8, out) == 0
+    assert list(out) == [8, 32, 896, 0, 384, 128, 128, 256]  # first pass of the headline launch: 3/4 of the batch at ppw 8
+    assert L.emu_geometry(16, 8, 8, 4, 0, 0, 4096, 16384, 4, out) == 0
+    assert list(out)[:3] == [4, 16, 1536] and list(out)[4:] == [768, 256, 512, 0]  # its column pass: ppw 4, 2, 1
+    assert L.emu_geometry(8, 0, 8, 0, 4, 1, 1 << 30, 8192, 64, out) == 0 and out[5] == 0  # beyond blockIdx.y: no taper, sliced

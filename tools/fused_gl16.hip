@@ -77,6 +77,7 @@ struct FusedExec {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     __device__ __forceinline__ uint32_t pg_base() const { return ctx.pg_base; }
+    __device__ __forceinline__ int ppw() const { return ctx.ppw; }
     __device__ __forceinline__ W *lds() { return tile; }
 
     __device__ __forceinline__ bool iter_begin(int it) {
@@ -204,6 +205,7 @@ hipError_t launch_fused_gl16(const void *in, void *out, const void *tw, size_t b
     fa.a.s0 = 0;
     fa.a.batch = (uint32_t) batch;
     fa.a.ppw = (int) (batch / (8 * A_SETS)) + 1;
+    fa.a.tp = Taper{{0xFFFFFFFFu, 0, 0, 0}};  // no taper: every workgroup streams ppw groups
     fa.a.log_ul = 0;
     fa.a.log_uh = CfgA::LOG_U;  // 8 units of 256 words per workgroup
     fa.a.log_up = 0;
@@ -214,6 +216,7 @@ hipError_t launch_fused_gl16(const void *in, void *out, const void *tw, size_t b
     fa.b.s0 = 8;
     fa.b.batch = (uint32_t) batch;
     fa.b.ppw = (int) (batch / (8 * B_SETS)) + 1;
+    fa.b.tp = Taper{{0xFFFFFFFFu, 0, 0, 0}};
     hipLaunchKernelGGL(fused_gl16_kernel, dim3(8 * SLOTS), dim3(NT), 0, s, fa);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
