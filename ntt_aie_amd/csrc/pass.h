@@ -50,6 +50,12 @@
 #ifndef NTT_PPW_CAP_CONTIG_INV
 #define NTT_PPW_CAP_CONTIG_INV 8  // cap on polynomials per workgroup, inverse radix-8 CONTIG passes (see PassCfg::PPW_CAP)
 #endif
+#ifndef NTT_PPW_CAP_CONTIG_FWD
+#define NTT_PPW_CAP_CONTIG_FWD 8
+#endif
+#ifndef NTT_PPW_CAP_COL_FWD
+#define NTT_PPW_CAP_COL_FWD 4
+#endif
 #ifndef NTT_PPW_CAP_COL_INV
 #define NTT_PPW_CAP_COL_INV 4  // ... inverse Goldilocks column passes
 #endif
@@ -164,8 +170,8 @@ struct PassCfg {
     // Most polynomials a workgroup streams through its resident twiddles (tools/ppw_sweep.py, N = 2^13 .. 2^17, batches
     // 2048 .. 16384): the 256-thread Goldilocks LDS-DMA first passes are fastest at 8 whatever the batch (16 costs 5-6 % at
     // batch 8192), the Goldilocks column passes at 4 (8 costs 4 %); the other kernels keep the workgroup-count rule alone.
-    static constexpr int PPW_CAP = sizeof(W) == 8 ? (CONTIG ? (LOG_E_ < 4 && LOG_NT_ == 8 ? (INV ? NTT_PPW_CAP_CONTIG_INV : 8) : 64)
-                                                              : (INV ? NTT_PPW_CAP_COL_INV : 4))
+    static constexpr int PPW_CAP = sizeof(W) == 8 ? (CONTIG ? (LOG_E_ < 4 && LOG_NT_ == 8 ? (INV ? NTT_PPW_CAP_CONTIG_INV : NTT_PPW_CAP_CONTIG_FWD) : 64)
+                                                              : (INV ? NTT_PPW_CAP_COL_INV : NTT_PPW_CAP_COL_FWD))
                                                    : 64;
     static NTT_HD uint32_t lds_index(uint32_t lin) {
         if (CDMA) return lin + ((lin >> 8) << 4);  // 16 words after every 16 rows of 16 words

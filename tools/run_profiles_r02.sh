@@ -22,6 +22,20 @@ cd $GRAFT_REPO_ROOT
 cat $S/r02_sq_real_vs_floor.txt
 rm -rf gpurun_out/sq_real gpurun_out/sq_floor
 python3 tools/bench_configs.py > $S/r02_bench_all_configs.jsonl 2> gpurun_out/cfg.err
+# second half of round 2 (linear tile copies, per-exchange syncs, tapered launch tail) against the library as of 59eb281, same process:
+# ab/libntt_r02a.so = tools/ab_build_rev.sh r02a 59eb281
+{ V="r02a_59eb281=ab/libntt_r02a.so final=ntt_aie_amd/libntt_hip.so"
+  python3 tools/ab_latency.py $V
+  python3 tools/ab_latency.py --inverse $V
+  python3 tools/ab_latency.py --p 12289 --g 11 $V
+  python3 tools/ab_latency.py --batch 65536 --k 10 $V
+  python3 tools/ab_latency.py --p 998244353 --g 3 --batch 65536 --k 10 $V
+  python3 tools/ab_latency.py --logn 8 --p 3329 --g 3 --batch 1048576 --k 10 $V
+  python3 tools/ab_latency.py --logn 12 --p 18446744069414584321 --g 7 --word-bytes 8 --batch 16384 --k 10 $V
+  python3 tools/ab_latency.py --logn 16 --p 18446744069414584321 --g 7 --word-bytes 8 --batch 4096 --k 10 $V
+  python3 tools/ab_latency.py --logn 20 --p 18446744069414584321 --g 7 --word-bytes 8 --batch 512 --k 5 $V
+} 2>&1 | grep -v amdgpu.ids > $S/r02_ab_second_half.txt
+cat $S/r02_ab_second_half.txt
 python3 tools/chunk_streams.py 128 512 > $S/r02_chunk_streams.txt 2>&1
 cp gpurun_out/profiles_r02/../profiles_r02/* $S/ 2>/dev/null || true
 ls -la $S
