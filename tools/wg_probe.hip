@@ -4,6 +4,7 @@
 // build: hipcc --offload-arch=gfx950 -O2 tools/wg_probe.hip -o tools/wg_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <vector>
 #include <map>
@@ -12,7 +13,7 @@
 struct Rec { uint32_t hw_id, lds_alloc, xcc; uint64_t t0, t1; };
 
 __global__ __launch_bounds__(256) void probe(Rec *out, int spin) {
-    __shared__ uint32_t tile[17408 / 4];
+    extern __shared__ uint32_t tile[];
     uint32_t hw, la, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_LDS_ALLOC)" : "=s"(la));
@@ -31,12 +32,13 @@ __global__ __launch_bounds__(256) void probe(Rec *out, int spin) {
     }
 }
 
-int main() {
-    const int WGS = 1024;
+int main(int argc, char **argv) {
+    const int WGS = argc > 2 ? atoi(argv[2]) : 1024;
+    const int LDS = argc > 1 ? atoi(argv[1]) : 17408;  // bytes of LDS per workgroup
     Rec *d;
     hipMalloc(&d, WGS * sizeof(Rec));
     for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL(probe, dim3(WGS), dim3(256), 0, 0, d, 20000);
+        hipLaunchKernelGGL(probe, dim3(WGS), dim3(256), LDS, 0, d, 20000);
         hipDeviceSynchronize();
     }
     std::vector<Rec> h(WGS);
@@ -63,5 +65,14 @@ int main() {
         }
     }
     for (auto &kv : hist) printf("%d CUs hold %zu workgroups\n", kv.second, kv.first);
+    std::map<int, int> conc;  // workgroups of a CU that started before the first one of that CU ended
+    for (auto &kv : by_cu) {
+        uint64_t first_end = ~0ull;
+        for (int i : kv.second) first_end = std::min(first_end, h[i].t1);
+        int n = 0;
+        for (int i : kv.second) n += h[i].t0 < first_end;
+        conc[n]++;
+    }
+    for (auto &kv : conc) printf("LDS %d B per workgroup: %d CUs ran %d workgroups at once\n", LDS, kv.second, kv.first);
     return 0;
 }
