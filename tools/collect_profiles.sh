@@ -32,5 +32,9 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 echo "sq done"
 S=$(find "$OUT/sq" -name '*counter_collection.csv' | head -1)
 python3 $ROOT/tools/sq_summary.py "$S" > "$SUM/${TAG}_sq_counters.json"
+# the judged bench line once more, now that the counter summaries of THIS build exist: bench.py quotes roofline.traffic and the VALU
+# counters only from profiles/<tag>_*.json stamped with the tree's kernel-source hash
+cp "$SUM/${TAG}_pmc_traffic.json" "$SUM/${TAG}_sq_counters.json" "$ROOT/profiles/"
+python3 $ROOT/bench.py > "$SUM/${TAG}_bench.json"
 head -c 1500 "$SUM/${TAG}_pmc_traffic.json"; echo
 ls -la "$SUM"
