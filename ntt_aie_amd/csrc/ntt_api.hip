@@ -91,6 +91,7 @@ struct ntt_plan {
     uint32_t target_wgs;      // workgroups per launch the batch loop of a CONTIG pass is sized for
     uint32_t target_wgs_col;  // ... of a column pass (shorter loops win there)
     int dbg;            // experiment build only (NTT_DEBUG_FLAGS); always 0 in the product
+    int only_pass;      // experiment build only (NTT_ONLY_PASS=k): ntt_forward launches pass k alone (power / clock of one kernel); -1 in the product
     int fused;          // experiment build only (NTT_FUSED=1): N = 2^16 Goldilocks forward through the XCD-local fused launch
     void *d_fused_ctl;  // counters of the fused launch (plan-owned; null in the product)
     size_t fused_max_batch;
@@ -148,6 +149,9 @@ int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
     }
 #endif
     for (const PassDesc &pd : pl->passes) {
+#if defined(NTT_EXPERIMENT)
+        if (pl->only_pass >= 0 && (int) (&pd - &pl->passes.front()) != pl->only_pass) continue;  // timing experiment: outputs meaningless
+#endif
         RoctxRange pass("fwd pass", pd.contig, pd.s0, pd.log_m);
         ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
         a.skip_if = skip_if;
@@ -245,6 +249,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     // column passes: 16384 (their tile streams 8 polynomials per workgroup at N = 2^16, batch 4096, instead of 16): -4 %
     pl->target_wgs_col = 2 * pl->target_wgs;
     pl->dbg = 0;
+    pl->only_pass = -1;
     pl->fused = 0;
     pl->d_fused_ctl = nullptr;
     pl->fused_max_batch = 0;
@@ -262,6 +267,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
         if (v > 0 && v < (1 << 24)) pl->target_wgs_col = (uint32_t) v;
     }
     if (const char *e = getenv("NTT_DEBUG_FLAGS")) pl->dbg = atoi(e);
+    if (const char *e = getenv("NTT_ONLY_PASS")) pl->only_pass = atoi(e);
     if (const char *e = getenv("NTT_FUSED")) pl->fused = atoi(e);
     if (const char *e = getenv("NTT_PLAN_SPLIT")) {  // "8,6,6" = CONTIG 8 stages + two 6-stage column passes
         std::vector<PassDesc> v;

@@ -24,12 +24,15 @@ y = torch.empty_like(x)
 exp = _lib.open_library(os.path.join(ROOT, "ntt_aie_amd", "libntt_hip_exp.so"))
 
 
-def plan(dbg):
+def plan(dbg, only_pass=None):
     if dbg:
         os.environ["NTT_DEBUG_FLAGS"] = str(dbg)
+    if only_pass is not None:
+        os.environ["NTT_ONLY_PASS"] = str(only_pass)
     h = C.c_void_p()
     assert exp.ntt_plan_create(C.byref(h), 16, GOLDILOCKS, 8, 0) == 0
     os.environ.pop("NTT_DEBUG_FLAGS", None)
+    os.environ.pop("NTT_ONLY_PASS", None)
     assert exp.ntt_plan_generate_twiddles(h, 0, 7) == 0
     return h
 
@@ -78,3 +81,10 @@ probe("forward (real)", lambda: exp.ntt_forward(h0, x.data_ptr(), y.data_ptr(), 
 probe("forward (L2 loads, no stores)", lambda: exp.ntt_forward(h3, x.data_ptr(), y.data_ptr(), 4096, 0, s))
 probe("copy (xor kernel)", lambda: torch.bitwise_xor(x, 1, out=y))
 probe("forward (real) again", lambda: exp.ntt_forward(h0, x.data_ptr(), y.data_ptr(), 4096, 0, s))
+# each pass kernel alone (NTT_ONLY_PASS, experiment build): does one of the two cost more power per byte than the other?
+hp0, hp1 = plan(0, 0), plan(0, 1)
+probe("CONTIG pass alone (stages 0-7)", lambda: exp.ntt_forward(hp0, x.data_ptr(), y.data_ptr(), 4096, 0, s))
+probe("column pass alone (stages 8-15)", lambda: exp.ntt_forward(hp1, x.data_ptr(), y.data_ptr(), 4096, 0, s))
+hf0, hf1 = plan(3, 0), plan(3, 1)
+probe("CONTIG pass alone, L2 loads, no stores", lambda: exp.ntt_forward(hf0, x.data_ptr(), y.data_ptr(), 4096, 0, s))
+probe("column pass alone, L2 loads, no stores", lambda: exp.ntt_forward(hf1, x.data_ptr(), y.data_ptr(), 4096, 0, s))
