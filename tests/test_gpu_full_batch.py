@@ -263,3 +263,34 @@ def test_column_pass_beyond_grid_limit_is_sliced(eng, oracle):
     assert np.array_equal(eng.to_host(X[rows]), oracle.ntt(eng.to_host(x[rows]), T, p, nthreads=4))
     back = pl.inverse(X)
     assert torch.equal(back, x)
+
+
+@pytest.mark.parametrize("wb,p,g,logn,batch", [(8, GOLD, 7, 16, 4099), (8, GOLD, 7, 13, 33001), (8, GOLD, 7, 12, 16391), (8, GOLD, 7, 18, 1027),
+                                               (4, 3221225473, 5, 12, 65539), (4, 998244353, 3, 16, 8197), (4, 3329, 3, 8, 1048583),
+                                               (4, 12289, 11, 5, 3000017)])
+def test_tapered_launch_ragged_batches(eng, oracle, wb, p, g, logn, batch):
+    """Long launches end with rows that stream ppw/2, ppw/4, ppw/8 polynomial groups (pass.h: struct Taper), and the linear tile
+    copies rely on the range check of a buffer descriptor that ends at the end of the [batch][N] buffer to drop the chunks of
+    polynomials past a ragged batch.  Odd (prime) batches at sizes of every kernel family: rows on both sides of every taper
+    level's first group against the oracle, the whole batch by round trip, and a guard polynomial behind the batch -- in the
+    output of the forward, the inverse and the in-place transform -- must come back untouched."""
+    import torch
+
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, wb, 0)
+    T = pl.make_roots(g)
+    pl.set_twiddles(T)
+    x = _device_batch(torch, batch + 1, n, p, wb, logn + batch % 97)  # one guard polynomial behind the batch
+    guard = x[batch].clone()
+    out = torch.full_like(x, 0x5A5A5A5A)
+    X = pl.forward(x[:batch], out[:batch])
+    assert X.data_ptr() == out.data_ptr()
+    marks = sorted({0, 1, batch - 1, batch - 2, *(int(batch * f) + d for f in (0.5, 0.75, 0.875, 0.9375) for d in (-1, 0, 1))})
+    assert np.array_equal(eng.to_host(X[marks]), oracle.ntt(eng.to_host(x[marks]), T, p, nthreads=8))
+    assert bool((out[batch] == 0x5A5A5A5A).all()), "forward wrote behind the batch"
+    back = torch.full_like(x, 0x3C3C3C3C)
+    pl.inverse(X, back[:batch])
+    assert torch.equal(back[:batch], x[:batch])
+    assert bool((back[batch] == 0x3C3C3C3C).all()), "inverse wrote behind the batch"
+    pl.forward(x[:batch], x[:batch])  # in place
+    assert torch.equal(x[:batch], X) and torch.equal(x[batch], guard)
