@@ -50,6 +50,9 @@
 #ifndef NTT_PPW_CAP_CONTIG_INV
 #define NTT_PPW_CAP_CONTIG_INV 8  // cap on polynomials per workgroup, inverse radix-8 CONTIG passes (see PassCfg::PPW_CAP)
 #endif
+#ifndef NTT_LINEAR_RUN_BYTES
+#define NTT_LINEAR_RUN_BYTES 128  // see PassCfg::LINEAR_BOTH
+#endif
 #ifndef NTT_PPW_CAP_CONTIG_FWD
 #define NTT_PPW_CAP_CONTIG_FWD 8
 #endif
@@ -82,7 +85,7 @@ enum { LAYOUT_NATURAL = 0, LAYOUT_AIE_BLOCK16 = 1 };
 
 // src/test.cpp:69-71 ans_order as an index rule: swap the bits inside each 2-bit
 // half of the 4-bit block index (1<->2, 4<->8, 5<->10, 6<->9, 7<->11, 13<->14).
-NTT_HD uint32_t aie_block16(uint32_t b) { return ((b & 5u) << 1) | ((b >> 1) & 5u); }
+NTT_HD constexpr uint32_t aie_block16(uint32_t b) { return ((b & 5u) << 1) | ((b >> 1) & 5u); }
 
 template <int I, int N, class Fn>
 NTT_HD void static_for(Fn &&f) {
@@ -127,8 +130,16 @@ struct PassCfg {
     // global loads / stores straight between HBM and the round registers are
     // coalesced when lanes run along columns (column pass) or along the low mid
     // bits (high window); otherwise the tile is staged linearly through LDS.
-    static constexpr bool DIRECT_LOAD = !CONTIG || R == 1 || INV;
-    static constexpr bool DIRECT_STORE = !CONTIG || R == 1 || !INV;
+    // ... unless the unit is so small that such an access moves only 2^LOG_Q words per polynomial before it jumps to the next
+    // one (N = 2^3 .. 2^6: thread-per-polynomial loads touched every 64-byte line once per WORD -- N = 16 took 16-31 ms per
+    // 4 GiB where N = 256 takes 1.7): runs shorter than one 128-byte line go through the linear LDS staging in BOTH directions
+    // (same-process sweep of the threshold, tools/ab_latency.py: 32-byte runs -8 .. -15 %, 64-byte runs 0 .. -2 %, 128-byte
+    // runs of 8-byte words +4.5 %).  Plain pass kernels only: the product pass and the fused-product twins, ALLOW_DMA_ = false,
+    // keep their register paths; a chunk of the linear copy is 16 bytes, so N = 2 of 4-byte words stays direct.
+    static constexpr bool LINEAR_BOTH = CONTIG && ALLOW_DMA_ && E * sizeof(W) >= 16 && (sizeof(W) << (LOG_M - LOG_E)) < NTT_LINEAR_RUN_BYTES;
+    static constexpr int LIN_AUX = (sizeof(W) == 4 || LINEAR_BOTH) ? 2 : 0;  // cache policy of the linear copies (2 = nt), see linear_rsrc
+    static constexpr bool DIRECT_LOAD = !CONTIG || ((R == 1 || INV) && !LINEAR_BOTH);
+    static constexpr bool DIRECT_STORE = !CONTIG || ((R == 1 || !INV) && !LINEAR_BOTH);
     // A CONTIG unit of <= 1024 words is owned by <= 64 consecutive threads, i.e. by ONE wave, and the
     // linear staging is wave-segmented too: every LDS word is written and read by the same wave, so
     // the exchanges need no workgroup barrier (LDS operations of a wave execute in order) and the
@@ -622,12 +633,10 @@ struct LinearGeom {
     NTT_HD bool active(const PassArgs<Cfg> &a, int i) const { return (pg0 | ((lin(i) >> Cfg::LOG_M) >> a.log_uh)) < a.batch; }
 };
 
-// Cache policy of the linear tile copies (aux bits: 2 = nt).  Measured same-process (tools/ab_latency.py): non-temporal is worth
-// -6.5 % on 4-byte words at N = 2^8, batch 2^20 and neutral on the other 4-byte shapes; on 8-byte words (N = 2^12, batch 16384)
-// it measured +1.5 %, so those keep the default policy.
-#ifndef NTT_AUX_LIN
-#define NTT_AUX_LIN(W) (sizeof(W) == 4 ? 2 : 0)
-#endif
+// Cache policy of the linear tile copies (aux bits: 2 = nt), PassCfg::LIN_AUX.  Measured same-process with ONE output buffer
+// (tools/ab_latency.py): non-temporal is worth -3 % on 4-byte words at N = 2^4 and 2^8 (batch 2^24 / 2^20), -1 % at N = 2^16 and
+// nothing at N = 2^12; on 8-byte words -4 % at N = 2^5 (a unit staged linearly in both directions), -1.5 % at N = 2^8, but +2 %
+// at N = 2^12: 4-byte words and the small two-way units use it, the other 8-byte tiles keep the default policy.
 #if defined(__HIP_DEVICE_COMPILE__)
 // Descriptor over [base, end of the [batch][N] buffer): chunks of polynomials past the batch (ragged tail of a workgroup
 // that holds several polynomials) lie beyond it, so their loads return zero and their stores are dropped by the
@@ -654,7 +663,7 @@ NTT_HD void phase_linear_issue(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     const __amdgpu_buffer_rsrc_t rs = linear_rsrc<Cfg>(a.in, a, g.tile0);
 #pragma unroll
     for (int i = 0; i < G::ITER; ++i) {
-        const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (uint32_t) i * G::STEP * (uint32_t) sizeof(typename Cfg::W), NTT_AUX_LIN(typename Cfg::W));
+        const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (uint32_t) i * G::STEP * (uint32_t) sizeof(typename Cfg::W), Cfg::LIN_AUX);
         Ch v;
         __builtin_memcpy(&v, &d, 16);
 #pragma unroll
@@ -664,7 +673,7 @@ NTT_HD void phase_linear_issue(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
         const __amdgpu_buffer_rsrc_t rs2 = linear_rsrc<Cfg>(a.in2, a, g.tile0);
 #pragma unroll
         for (int i = 0; i < G::ITER; ++i) {
-            const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(rs2, voff, (uint32_t) i * G::STEP * (uint32_t) sizeof(typename Cfg::W), NTT_AUX_LIN(typename Cfg::W));
+            const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(rs2, voff, (uint32_t) i * G::STEP * (uint32_t) sizeof(typename Cfg::W), Cfg::LIN_AUX);
             Ch w;
             __builtin_memcpy(&w, &d, 16);
 #pragma unroll
@@ -723,7 +732,7 @@ NTT_HD void phase_linear_store(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg
         const Ch v = *reinterpret_cast<const Ch *>(lds + g.lds(i));
         u32x4_t d;
         __builtin_memcpy(&d, &v, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, (uint32_t) i * G::STEP * (uint32_t) sizeof(typename Cfg::W), NTT_AUX_LIN(typename Cfg::W));
+        __builtin_amdgcn_raw_buffer_store_b128(d, rs, voff, (uint32_t) i * G::STEP * (uint32_t) sizeof(typename Cfg::W), Cfg::LIN_AUX);
     }
 #else
 #pragma unroll
@@ -804,9 +813,25 @@ NTT_HD void phase_dma_wait() {
 #endif
 }
 
+// does this pass see the transform-domain layout AIE_BLOCK16 (elem_eff): the pass that holds the top stage, radix-16 rounds
+template <class Cfg>
+NTT_HD bool block16_here(const PassArgs<Cfg> &a) {
+    return Cfg::LOG_E == 4 && a.layout == LAYOUT_AIE_BLOCK16 && (a.s0 + Cfg::LOG_M == a.n);
+}
+
+// perm: the tile holds the polynomial in AIE_BLOCK16 order (a linearly staged inverse input, or forward output): element e of
+// the outermost round is block aie_block16(e)
 template <class Cfg, int r>
-NTT_HD void phase_lds_read(Ctx<Cfg> &c, const typename Cfg::W *lds) {
+NTT_HD void phase_lds_read(Ctx<Cfg> &c, const typename Cfg::W *lds, bool perm = false) {
     const typename Cfg::W *p = lds + c.lds_base[r];
+    if (Cfg::LOG_E == 4 && perm) {
+#pragma unroll
+        for (int e = 0; e < Cfg::E; ++e) {
+            NTT_LDS_ACCESS(p + lds_elem_off<Cfg>(r, (int) aie_block16((uint32_t) e & 15u)), c.tid, false);
+            c.x[e] = p[lds_elem_off<Cfg>(r, (int) aie_block16((uint32_t) e & 15u))];
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
         NTT_LDS_ACCESS(p + lds_elem_off<Cfg>(r, e), c.tid, false);
@@ -815,8 +840,16 @@ NTT_HD void phase_lds_read(Ctx<Cfg> &c, const typename Cfg::W *lds) {
 }
 
 template <class Cfg, int r>
-NTT_HD void phase_lds_write(Ctx<Cfg> &c, typename Cfg::W *lds) {
+NTT_HD void phase_lds_write(Ctx<Cfg> &c, typename Cfg::W *lds, bool perm = false) {
     typename Cfg::W *p = lds + c.lds_base[r];
+    if (Cfg::LOG_E == 4 && perm) {
+#pragma unroll
+        for (int e = 0; e < Cfg::E; ++e) {
+            NTT_LDS_ACCESS(p + lds_elem_off<Cfg>(r, (int) aie_block16((uint32_t) e & 15u)), c.tid, true);
+            p[lds_elem_off<Cfg>(r, (int) aie_block16((uint32_t) e & 15u))] = c.x[e];
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
         NTT_LDS_ACCESS(p + lds_elem_off<Cfg>(r, e), c.tid, true);
@@ -1077,8 +1110,8 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.each([&](C &c) { phase_linear_commit<Cfg>(c, a, tile, it); });
             // round 0 of thread t reads words [E*t, E*t + E) of the tile: the segment its own wave has just staged, so this
             // hand-off is wave-local whatever the unit size (as with the LDS-DMA tiles); the later exchanges keep their barrier
-            ex.sync(std::true_type{});
-            ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, tile); });
+            ex.sync(std::integral_constant<bool, FIRST == 0 || Cfg::WAVE_LOCAL>{});  // (an inverse pass staged this way is a small, wave-local unit)
+            ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, tile, Cfg::INV && block16_here<Cfg>(a)); });
         }
         static_for<0, R>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
@@ -1103,8 +1136,8 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.each([&](C &c) { phase_store_direct<Cfg, LAST>(c, a, it); });
             prio_down<2>();
         } else {
-            ex.each([&](C &c) { phase_lds_write<Cfg, LAST>(c, tile); });
-            ex.sync(std::true_type{});  // round 0's words of a wave's threads are that wave's segment of the linear copy
+            ex.each([&](C &c) { phase_lds_write<Cfg, LAST>(c, tile, !Cfg::INV && block16_here<Cfg>(a)); });
+            ex.sync(std::integral_constant<bool, LAST == 0 || Cfg::WAVE_LOCAL>{});  // round 0's words of a wave's threads are that wave's segment of the linear copy
             ex.each([&](C &c) { phase_linear_store<Cfg>(c, a, tile, it); });
         }
         ex.iter_done(it);  // fused schedule: publish the previous polynomial's tile

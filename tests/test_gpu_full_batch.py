@@ -267,7 +267,8 @@ def test_column_pass_beyond_grid_limit_is_sliced(eng, oracle):
 
 @pytest.mark.parametrize("wb,p,g,logn,batch", [(8, GOLD, 7, 16, 4099), (8, GOLD, 7, 13, 33001), (8, GOLD, 7, 12, 16391), (8, GOLD, 7, 18, 1027),
                                                (4, 3221225473, 5, 12, 65539), (4, 998244353, 3, 16, 8197), (4, 3329, 3, 8, 1048583),
-                                               (4, 12289, 11, 5, 3000017)])
+                                               (4, 12289, 11, 5, 3000017), (4, 3329, 3, 4, 5000011), (8, GOLD, 7, 3, 3000017),
+                                               (8, GOLD, 7, 1, 7000003), (4, 3329, 3, 2, 9000011)])
 def test_tapered_launch_ragged_batches(eng, oracle, wb, p, g, logn, batch):
     """Long launches end with rows that stream ppw/2, ppw/4, ppw/8 polynomial groups (pass.h: struct Taper), and the linear tile
     copies rely on the range check of a buffer descriptor that ends at the end of the [batch][N] buffer to drop the chunks of
@@ -294,3 +295,25 @@ def test_tapered_launch_ragged_batches(eng, oracle, wb, p, g, logn, batch):
     assert bool((back[batch] == 0x3C3C3C3C).all()), "inverse wrote behind the batch"
     pl.forward(x[:batch], x[:batch])  # in place
     assert torch.equal(x[:batch], X) and torch.equal(x[batch], guard)
+
+
+@pytest.mark.parametrize("wb,p,g,logn,batch", [(4, 3329, 3, 4, 2000003), (4, 3221225473, 5, 5, 1000003), (4, 998244353, 3, 6, 500009),
+                                               (8, GOLD, 7, 4, 1000003), (8, GOLD, 7, 5, 500009), (8, GOLD, 7, 7, 100003)])
+def test_small_units_block16_layout_full_batch(eng, oracle, wb, p, g, logn, batch):
+    """Units whose direct accesses would move less than one 128-byte line per polynomial are staged through LDS in both
+    directions (PassCfg::LINEAR_BOTH); there the AIE_BLOCK16 order (src/test.cpp:69-71) is applied inside the tile
+    (phase_lds_write / phase_lds_read with perm) instead of by the global store / load: forward to block order and the inverse
+    from it, sampled rows against the oracle and the whole odd batch by round trip."""
+    import torch
+
+    n = 1 << logn
+    pl = eng.NTTPlan(logn, p, wb, 0)
+    T = pl.make_roots(g)
+    pl.set_twiddles(T)
+    x = _device_batch(torch, batch, n, p, wb, 31 * logn + wb)
+    rows = [0, 1, 255, 256, batch // 2, batch - 257, batch - 2, batch - 1]
+    X = pl.forward(x, layout=eng.LAYOUT_AIE_BLOCK16)
+    assert np.array_equal(eng.to_host(X[rows]), oracle.block16(oracle.ntt(eng.to_host(x[rows]), T, p, nthreads=4)))
+    assert torch.equal(pl.inverse(X, layout=eng.LAYOUT_AIE_BLOCK16), x)
+    Xn = pl.forward(x)
+    assert np.array_equal(eng.to_host(Xn[rows]), oracle.ntt(eng.to_host(x[rows]), T, p, nthreads=4))
