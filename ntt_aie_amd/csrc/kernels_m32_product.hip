@@ -1,10 +1,12 @@
 // kernels_m32_product.hip -- the same fused middle pass for 4-byte words (any odd p < 2^32): radix-16 rounds, unit sizes
-// 2^5 .. 2^12; for N <= 2^12 the launch is the whole negacyclic product.
+// 2^6 .. 2^12 (used; 2^5 instantiated for the host-model test); for N <= 2^12 the launch is the whole negacyclic product.
 #include "product_kernel.inc"
 
 namespace ntt {
 
-bool have_m32_product_mid(int log_m) { return log_m >= 5 && log_m <= 12; }
+// (2^5 has a kernel too, but its register loads and stores move 8 bytes per polynomial at a time: 3.9 ms per GiB of operands
+// against 1.4 ms for the three separate launches, whose small units are staged through LDS -- tools/polymul_small.py)
+bool have_m32_product_mid(int log_m) { return log_m >= 6 && log_m <= 12; }
 
 hipError_t launch_m32_product_mid(int log_m, const ErasedArgs &a, hipStream_t s) {
     switch (log_m) {
