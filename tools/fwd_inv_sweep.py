@@ -8,7 +8,7 @@ import torch
 from ntt_aie_amd import NTTPlan
 
 wb = int(sys.argv[1])
-p, g = (0xFFFFFFFF00000001, 7) if wb == 8 else (3221225473, 5)
+p, g = (0xFFFFFFFF00000001, 7) if wb == 8 else (int(os.environ.get("NTT_SWEEP_P", "3221225473")), int(os.environ.get("NTT_SWEEP_G", "5")))
 
 
 def timeit(fn, steps=8, warmup=3):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Negacyclic product and pointwise product at small sizes, 1 GiB per operand: the sizes below the product kernel's range
+"""Negacyclic product and pointwise product at small sizes (or the sizes given: polymul_small.py logn ...), 1 GiB per operand: the sizes below the product kernel's range
 (Goldilocks N < 2^7, 4-byte words N < 2^5) fold only the pointwise leg into the forward pass.  One JSON line per shape."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ import bench_configs as B
 from ntt_aie_amd import NTTPlan
 
 for wb, p, g in ((8, B.GOLD, 7), (4, 998244353, 3)):
-    for logn in (2, 3, 4, 5, 6, 7, 8, 10):
+    for logn in ([int(v) for v in sys.argv[1:]] or [2, 3, 4, 5, 6, 7, 8, 10]):
         n = 1 << logn
         batch = (1 << 30) // (n * wb)
         plan = NTTPlan(logn, p, wb, 0)
