@@ -55,16 +55,27 @@ inline uint64_t bitrev(uint64_t x, int bits) {
     return r;
 }
 
-// Split logn stages into HBM passes: one contiguous pass of <= 12 stages (tile =
-// 4096 words in LDS) followed by column passes of 4..8 stages (<= 256 rows x one 128-byte segment).
+// Split logn stages into HBM passes: one contiguous pass of <= 12 stages (13 for 4-byte words; tile =
+// 4096 / 8192 words in LDS) followed by column passes of 4..8 stages (<= 256 rows x one 128-byte segment).
 // Always the fewest passes; for the two-pass sizes the split is the measured optimum
 // (tools/split_sweep.py, profiles/r01_g_split_sweep.jsonl): a pass costs about max(VALU, memory) plus a
 // quarter of the smaller one; a light column pass (6-7 stages) streams at the device's copy rate, and an
 // 8-stage first pass is the sweet spot of both CONTIG kernels.
+// 4-byte words also have a 13-stage contiguous pass (8192 words = 32 KiB per tile, 512 threads x 16 words, rounds of
+// 4 + 4 + 4 + 1 stages; the 8-byte twin would hold one workgroup per CU): N = 2^13 in ONE pass (2.08-2.63 ms per 4 GiB instead of
+// 3.19-3.24 in two; a single launch at batch 1: 6.5 instead of 8.1 us) and N = 2^21 in two (13 + 8: 3.80 instead of 4.84 ms);
+// 13 + 7 and 13 + 6 lose to 12 + 8 and 12 + 7 (same-process, tools/ab_latency.py with NTT_PLAN_SPLIT).
+constexpr int MAX_CONTIG_LOG_M_W4 = 13;
+
 inline std::vector<PassDesc> plan_passes(int n, int word_bytes = 8) {
     std::vector<PassDesc> v;
-    if (n <= MAX_CONTIG_LOG_M) {
+    if (n <= (word_bytes == 4 ? MAX_CONTIG_LOG_M_W4 : MAX_CONTIG_LOG_M)) {
         v.push_back({true, 0, n});
+        return v;
+    }
+    if (word_bytes == 4 && n == MAX_CONTIG_LOG_M_W4 + MAX_COL_LOG_M) {
+        v.push_back({true, 0, MAX_CONTIG_LOG_M_W4});
+        v.push_back({false, MAX_CONTIG_LOG_M_W4, MAX_COL_LOG_M});
         return v;
     }
     if (n <= MAX_CONTIG_LOG_M + MAX_COL_LOG_M) {

@@ -41,17 +41,17 @@ def _run(oracle, wb, logn, p, g, batch, inverse=0, layout=0, scale=1, tw=2048, o
 
 @pytest.mark.parametrize("wb,p,g", FIELDS)
 def test_single_pass_sizes(oracle, wb, p, g):
-    for logn in range(1, 13):
+    for logn in range(1, 14 if wb == 4 else 13):  # 4-byte words: N = 2^13 is one 13-stage pass too
         for inv in (0, 1):
-            for batch in (1, 19):
-                _run(oracle, wb, logn, p, g, batch, inverse=inv, layout=int(logn >= 4 and batch == 19), seed=logn)
+            for batch in (1, 19) if logn < 13 else (1, 3):
+                _run(oracle, wb, logn, p, g, batch, inverse=inv, layout=int(logn >= 4 and batch != 1), seed=logn)
 
 
 @pytest.mark.parametrize("wb,p,g", FIELDS[:2])
 def test_multi_pass_planner_splits(oracle, wb, p, g):
-    for logn in (13, 16, 17):
+    for logn in (13, 14, 16, 17) + ((21,) if wb == 4 else ()):  # 4-byte words: 2^21 = 13 + 8
         for inv in (0, 1):
-            _run(oracle, wb, logn, p, g, 3, inverse=inv, layout=1, tw=8, seed=logn, inplace=True)
+            _run(oracle, wb, logn, p, g, 3 if logn < 21 else 1, inverse=inv, layout=1, tw=8, seed=logn, inplace=True)
 
 
 @pytest.mark.parametrize("ov", [(8, 4), (8, 5), (7, 6), (8, 7), (8, 8), (9, 4), (10, 4), (11, 5), (12, 4), (5, 4), (4, 6), (5, 6), (6, 7),
@@ -71,7 +71,8 @@ def test_planner_covers_all_sizes():
         for logn in range(1, 29):
             k = emu_lib.lib().emu_plan(logn, wb, tri)
             passes = [(tri[3 * i], tri[3 * i + 1], tri[3 * i + 2]) for i in range(k)]
-            assert passes[0][0] == 1 and passes[0][1] == 0 and 1 <= passes[0][2] <= 12
+            top = 13 if wb == 4 else 12  # stages of the widest contiguous pass
+            assert passes[0][0] == 1 and passes[0][1] == 0 and 1 <= passes[0][2] <= top
             s0 = passes[0][2]
             if k > 1:
                 assert s0 >= (4 if wb == 8 else 5)  # column tiles are 16 / 32 words wide
@@ -79,7 +80,7 @@ def test_planner_covers_all_sizes():
                 assert contig == 0 and s == s0 and 4 <= m <= 8
                 s0 += m
             assert s0 == logn
-            assert k == (1 if logn <= 12 else 1 + -(-(logn - 12) // 8))  # fewest HBM passes
+            assert k == (1 if logn <= top else 1 + -(-(logn - top) // 8))  # fewest HBM passes
 
 
 def test_field_arithmetic_edges():
@@ -123,7 +124,7 @@ def test_fused_pointwise_first_pass(oracle):
 
 
 @pytest.mark.parametrize("wb,p,g,logn", [(8, GOLD, 7, l) for l in (7, 9, 10, 12, 13, 14, 16, 17, 18, 19, 20)] +
-                         [(4, 998244353, 3, l) for l in (5, 6, 8, 10, 11, 12, 13, 16, 17, 19)] +
+                         [(4, 998244353, 3, l) for l in (5, 6, 8, 10, 11, 12, 14, 16, 17, 19)] +
                          [(4, 2013265921, 31, 9), (4, 3221225473, 5, 7), (4, 3221225473, 5, 12), (4, 3221225473, 5, 14)])
 def test_product_fused_middle_pass(oracle, wb, p, g, logn):
     """The negacyclic product the way the device runs it when the first pass has a product kernel (pass.h: run_product_pass:

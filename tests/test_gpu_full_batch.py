@@ -140,9 +140,11 @@ def test_multi_iteration_batch_loops_goldilocks(eng, oracle, logn, batch):
 
 
 @pytest.mark.parametrize("p,g", [(998244353, 3), (3221225473, 5)])
-@pytest.mark.parametrize("logn,batch", [(12, 65536), (16, 8192), (20, 256)])
+@pytest.mark.parametrize("logn,batch", [(12, 65536), (13, 32771), (16, 8192), (20, 256), (21, 131)])
 def test_multi_iteration_batch_loops_u32(eng, oracle, p, g, logn, batch):
-    """4-byte words (lazy p < 2^30 and carry-select p >= 2^31 streams) at batches with ppw >= 2 in every pass."""
+    """4-byte words (lazy p < 2^30 and carry-select p >= 2^31 streams) at batches with ppw >= 2 in every pass; 2^13 is the
+    13-stage contiguous pass alone (512 threads x 16 words, 8192-word tile) and 2^21 the same pass + an 8-stage column pass."""
+    assert len(eng.NTTPlan(13, p, 4, 0).passes) == 1 and len(eng.NTTPlan(21, p, 4, 0).passes) == 2
     import torch
 
     n = 1 << logn
@@ -221,7 +223,7 @@ def test_single_pass_product_one_launch(eng, oracle, logn, batch):
 
 
 @pytest.mark.parametrize("p,g", [(998244353, 3), (3221225473, 5)])
-@pytest.mark.parametrize("logn,batch", [(6, 300007), (12, 16384), (16, 2048), (20, 64)])
+@pytest.mark.parametrize("logn,batch", [(6, 300007), (12, 16384), (13, 8209), (16, 2048), (20, 64), (21, 33)])
 def test_product_four_byte_words_full_batch(eng, oracle, p, g, logn, batch):
     """The product kernel for 4-byte words (kernels_m32_product.hip): one launch for N <= 2^12 (several polynomials per
     workgroup, ragged tail), fused middle + column passes above; lazy and carry-select butterfly streams."""
