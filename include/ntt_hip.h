@@ -143,9 +143,9 @@ int ntt_pointwise_mul(ntt_plan_t plan, const void *d_a, const void *d_b, void *d
  * c = Fwd( InvU(a) . InvU(b) . N^-1 ) with the unscaled inverse network InvU.  Sizes N >= 2^7
  * (Goldilocks) / N >= 2^6 (4-byte words) run the column passes (N >= 2^13 only) of both inverse transforms, then ONE
  * fused middle launch per unit of the first pass (last inverse pass of a and of b, word-by-word product, first forward
- * pass: 3 N words of HBM traffic instead of 7 N; for N <= 2^12 that launch is the whole product), then the forward
- * column passes; smaller sizes, and 4-byte words at N = 2^13 (one 13-stage pass, no product kernel for that unit), fold the
- * product into the load of the forward transform's first pass.  d_a and d_b are overwritten (scratch); d_out may alias d_a or d_b.  When d_b directly follows
+ * pass: 3 N words of HBM traffic instead of 7 N; for single-pass sizes that launch is the whole product), then the forward
+ * column passes (4-byte words: one launch up to N = 2^13); smaller sizes fold the product into the load of the forward
+ * transform's first pass.  d_a and d_b are overwritten (scratch); d_out may alias d_a or d_b.  When d_b directly follows
  * d_a in memory (one [2*batch][N] buffer) both operand transforms run as one launch per pass. */
 int ntt_polymul_negacyclic(ntt_plan_t plan, void *d_a, void *d_b, void *d_out,
                            size_t batch, void *stream);

@@ -39,7 +39,7 @@ hipError_t launch_m32_inv(bool contig, int log_m, const ErasedArgs &a, hipStream
 hipError_t launch_gl_product_mid(int log_m, const ErasedArgs &a, hipStream_t s);
 bool have_gl_product_mid(int log_m);   // Goldilocks: unit sizes 2^7 .. 2^12
 hipError_t launch_m32_product_mid(int log_m, const ErasedArgs &a, hipStream_t s);
-bool have_m32_product_mid(int log_m);  // 4-byte words: unit sizes 2^6 .. 2^12
+bool have_m32_product_mid(int log_m);  // 4-byte words: unit sizes 2^6 .. 2^13
 
 #if defined(NTT_EXPERIMENT)
 // Tools-side experiment, NOT part of libntt_hip.so (tools/fused_gl16.hip, libntt_hip_exp.so only):

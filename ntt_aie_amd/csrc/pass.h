@@ -1328,8 +1328,9 @@ struct ProductCfg {
 // (two rounds at least); only the innermost round's twiddles stay in registers, the others come from the LDS table.
 template <int LOG_M>
 struct ProductCfgM32 {
-    using CI = PassCfg<FieldM32, LOG_M, 0, true, true, 1, 4, 8, false>;
-    using CF = PassCfg<FieldM32, LOG_M, 0, true, false, 1, 4, 8, false>;
+    static constexpr int LOG_NT = LOG_M >= 13 ? 9 : 8;  // the 13-stage unit (8192 words) takes 512 threads
+    using CI = PassCfg<FieldM32, LOG_M, 0, true, true, 1, 4, LOG_NT, false>;
+    using CF = PassCfg<FieldM32, LOG_M, 0, true, false, 1, 4, LOG_NT, false>;
 };
 
 // ---- launch geometry shared by host planner and host model ---------------------

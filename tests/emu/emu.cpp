@@ -443,7 +443,7 @@ int emu_polymul_fused(int word_bytes, int logn, uint64_t p, const void *T_plain,
     const void *ti = word_bytes == 4 ? (const void *) ti32.data() : (const void *) ti64.data();
     const std::vector<PassDesc> passes = plan_passes(logn, word_bytes);
     const int m0 = passes[0].log_m;
-    if (word_bytes == 8 ? (m0 < 7 || m0 > 12) : (m0 < 5 || m0 > 12)) return -1;  // unit sizes the product kernels exist for
+    if (word_bytes == 8 ? (m0 < 7 || m0 > 12) : (m0 < 5 || m0 > 13)) return -1;  // unit sizes the product kernels exist for
     Erased e;
     memset(&e, 0, sizeof(e));
     e.p = (uint32_t) p;
@@ -477,7 +477,7 @@ int emu_polymul_fused(int word_bytes, int logn, uint64_t p, const void *T_plain,
     } else {
         switch (m0) {
 #define PM(M) case M: rc = run_product_mid<ProductCfgM32<M>>(logn, batch, target_wgs, a, b, out, ti, tf, pw, e); break;
-            PM(5) PM(6) PM(7) PM(8) PM(9) PM(10) PM(11) PM(12)
+            PM(5) PM(6) PM(7) PM(8) PM(9) PM(10) PM(11) PM(12) PM(13)
 #undef PM
             default: return -1;
         }

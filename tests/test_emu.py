@@ -124,7 +124,7 @@ def test_fused_pointwise_first_pass(oracle):
 
 
 @pytest.mark.parametrize("wb,p,g,logn", [(8, GOLD, 7, l) for l in (7, 9, 10, 12, 13, 14, 16, 17, 18, 19, 20)] +
-                         [(4, 998244353, 3, l) for l in (5, 6, 8, 10, 11, 12, 14, 16, 17, 19)] +
+                         [(4, 998244353, 3, l) for l in (5, 6, 8, 10, 11, 12, 13, 14, 16, 17, 19, 21)] +
                          [(4, 2013265921, 31, 9), (4, 3221225473, 5, 7), (4, 3221225473, 5, 12), (4, 3221225473, 5, 14)])
 def test_product_fused_middle_pass(oracle, wb, p, g, logn):
     """The negacyclic product the way the device runs it when the first pass has a product kernel (pass.h: run_product_pass:
@@ -134,7 +134,7 @@ def test_product_fused_middle_pass(oracle, wb, p, g, logn):
     target_wgs 8 makes the workgroups stream several polynomials (the batch loop and its prefetch hand-over)."""
     dt = np.uint32 if wb == 4 else np.uint64
     n = 1 << logn
-    batch = 37 if logn <= 12 else (3 if logn <= 17 else 2)  # small N: several polynomials per workgroup, ragged tail
+    batch = 37 if logn <= 12 else (3 if logn <= 17 else (2 if logn < 21 else 1))  # small N: several polynomials per workgroup, ragged tail
     T = oracle.make_table(2, n, p, g, wb)
     rng = np.random.default_rng(logn)
     a = (rng.integers(0, 2**63, size=(batch, n), dtype=np.uint64) % np.uint64(p)).astype(dt)
