@@ -277,7 +277,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
             char *end = nullptr;
             const long m = strtol(c, &end, 10);
             if (end == c) break;
-            if (v.empty()) ok = m >= 1 && m <= (word_bytes == 4 ? 13 : MAX_CONTIG_LOG_M);
+            if (v.empty()) ok = m >= 1 && m <= 13;
             else ok = m >= MIN_COL_LOG_M && m <= MAX_COL_LOG_M;
             v.push_back({v.empty(), s0, (int) m});
             s0 += (int) m;

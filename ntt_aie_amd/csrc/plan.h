@@ -73,7 +73,10 @@ inline std::vector<PassDesc> plan_passes(int n, int word_bytes = 8) {
         v.push_back({true, 0, n});
         return v;
     }
-    if (word_bytes == 4 && n == MAX_CONTIG_LOG_M_W4 + MAX_COL_LOG_M) {
+    // ... and both word sizes reach N = 2^21 in two passes, 13 + 8 (8-byte words: 4.40 instead of 4.80 ms per 4 GiB in three; their
+    // 13-stage pass re-reads its twiddles from L2 every round (128 VGPRs, two 512-thread workgroups per CU), which at N = 2^13 alone
+    // is worth -11 % at saturating batches but +22 % for a single polynomial, so 8-byte N = 2^13 stays 7 + 6)
+    if (n == MAX_CONTIG_LOG_M_W4 + MAX_COL_LOG_M) {
         v.push_back({true, 0, MAX_CONTIG_LOG_M_W4});
         v.push_back({false, MAX_CONTIG_LOG_M_W4, MAX_COL_LOG_M});
         return v;

@@ -273,6 +273,7 @@ int dispatch(bool contig, int log_m, const Erased &e) {
     case M:         \
         return run_cfg<ColPassCfg<F, M, INV>>(e);
     if (contig) {
+        if (log_m == 13) return run_cfg<PassCfg<F, 13, 0, true, INV, sizeof(typename F::W) == 4 ? 0xF : 0x8, 4, 9>>(e);  // pass_kernel.inc: ContigCfg13
         if (contig_log_e(log_m, sizeof(typename F::W), e.s0 + log_m == e.n) == 3) {
             if constexpr (!INV) {
                 if (e.in2 != nullptr) {  // fused product: the non-DMA twins (pass_kernel.inc)
@@ -294,9 +295,6 @@ int dispatch(bool contig, int log_m, const Erased &e) {
         switch (log_m) {
             CASE_CONTIG(1) CASE_CONTIG(2) CASE_CONTIG(3) CASE_CONTIG(4) CASE_CONTIG(5) CASE_CONTIG(6)
             CASE_CONTIG(7) CASE_CONTIG(8) CASE_CONTIG(9) CASE_CONTIG(10) CASE_CONTIG(11) CASE_CONTIG(12)
-            case 13:  // 4-byte words only (pass_kernel.inc: ContigCfg13)
-                if constexpr (sizeof(typename F::W) == 4) return run_cfg<PassCfg<F, 13, 0, true, INV, 0xF, 4, 9>>(e);
-                return -1;
             default: return -1;
         }
     }

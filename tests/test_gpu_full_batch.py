@@ -159,11 +159,12 @@ def test_multi_iteration_batch_loops_u32(eng, oracle, p, g, logn, batch):
     assert torch.equal(pl.inverse(f), a)
 
 
-@pytest.mark.parametrize("logn,batch", [(13, 5), (16, 3), (21, 2)])
+@pytest.mark.parametrize("logn,batch", [(13, 5), (16, 3), (21, 2), (22, 1)])
 def test_product_fused_middle_aliasing_and_three_pass(eng, oracle, logn, batch):
-    """The fused middle pass of the product (pass.h:run_product_pass) at odd batches, for a three-pass size (N = 2^21:
-    two inverse column passes, the fused middle, two forward column passes), and with the result buffer aliasing
-    either operand or neither -- all must give the oracle pipeline's words."""
+    """The fused middle pass of the product (pass.h:run_product_pass) at odd batches, for a three-pass size (N = 2^22:
+    two inverse column passes, the fused middle, two forward column passes), for N = 2^21 = 13 + 8 stages (no product kernel
+    for the 13-stage 8-byte unit: the pointwise leg is folded into the forward pass instead), and with the result buffer
+    aliasing either operand or neither -- all must give the oracle pipeline's words."""
     import torch
 
     p = GOLD

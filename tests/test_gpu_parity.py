@@ -353,13 +353,13 @@ def test_bench_json_contract():
 
 @pytest.mark.parametrize("wb,p,g", [(8, GOLD, 7), (4, 3221225473, 5), (4, 998244353, 3)])
 def test_three_pass_sizes(eng, oracle, wb, p, g):
-    """N = 2^21 and 2^22: three HBM passes (CONTIG + two column passes); 4-byte words reach 2^21 in two (13 + 8 stages)."""
+    """N = 2^21 and 2^22: three HBM passes (CONTIG + two column passes), except that 2^21 = 13 + 8 stages takes two."""
     dt = np.uint32 if wb == 4 else np.uint64
     for logn in (21, 22):
         n = 1 << logn
         T = oracle.make_roots(n, p, g, wb)
         pl = _plan(eng, logn, p, wb, T)
-        assert pl.hbm_passes == (2 if wb == 4 and logn == 21 else 3)
+        assert pl.hbm_passes == (2 if logn == 21 else 3)
         a = _rand(2, n, p, dt, logn)
         f = pl.forward(eng.to_device(a, "cuda:0"))
         assert np.array_equal(eng.to_host(f), oracle.ntt(a, T, p, nthreads=8))
