@@ -328,6 +328,21 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(logn, p, eng.table)
+        # BASELINE config 3 is forward + inverse: the inverse transform of the same batch, outside the timed region above
+        # (scaled by N^-1, natural order in and out), one event pair per step; measured LAST so that nothing it allocates or heats
+        # perturbs the roofline measurements above
+        x2 = torch.empty_like(x)
+        plan.forward(x, y, stream=stream)
+        for e0, e1 in evs:
+            e0.record(stream)
+            plan.inverse(y, x2, stream=stream)
+            e1.record(stream)
+        torch.cuda.synchronize()
+        inv_ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        out["inverse"] = {"ms_per_step_median": inv_ms[len(inv_ms) // 2], "ms_per_step_min": inv_ms[0],
+                          "NTT_per_s": batch / (inv_ms[len(inv_ms) // 2] * 1e-3),
+                          "round_trip_identical": bool(torch.equal(x2, x))}
+        del x2
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
