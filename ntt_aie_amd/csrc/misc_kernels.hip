@@ -9,6 +9,13 @@
 #include "field.h"
 #include "kernels.h"
 
+#ifndef NTT_PW_UNROLL
+#define NTT_PW_UNROLL 2
+#endif
+#ifndef NTT_PW_NT
+#define NTT_PW_NT 3  // bit 0: non-temporal loads, bit 1: non-temporal stores
+#endif
+
 namespace ntt {
 namespace {
 
@@ -26,7 +33,36 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const typename F::W *a, 
     using Ch = Vec<W, V>;
     const size_t nchunks = count / V;  // count is a multiple of N >= 2; tail handled below
     const size_t stride = (size_t) gridDim.x * blockDim.x;
-    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += stride) {
+    // every word is read once and written once: non-temporal accesses, NTT_PW_UNROLL chunks of each operand requested before the
+    // first product (same-process A/B in profiles/r02_pointwise.txt)
+    using u32x4 = unsigned int __attribute__((ext_vector_type(4)));
+    const u32x4 *pa = reinterpret_cast<const u32x4 *>(a), *pb = reinterpret_cast<const u32x4 *>(b);
+    u32x4 *pc = reinterpret_cast<u32x4 *>(c);
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (NTT_PW_UNROLL - 1) * stride < nchunks; i += NTT_PW_UNROLL * stride) {
+        u32x4 xs[NTT_PW_UNROLL], ys[NTT_PW_UNROLL];
+#pragma unroll
+        for (int u = 0; u < NTT_PW_UNROLL; ++u) {
+            xs[u] = (NTT_PW_NT & 1) ? __builtin_nontemporal_load(pa + i + u * stride) : pa[i + u * stride];
+            ys[u] = (NTT_PW_NT & 1) ? __builtin_nontemporal_load(pb + i + u * stride) : pb[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < NTT_PW_UNROLL; ++u) {
+            Ch x, y, z;
+            __builtin_memcpy(&x, &xs[u], 16);
+            __builtin_memcpy(&y, &ys[u], 16);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                W t = f.mul_plain(x.v[k], y.v[k]);
+                z.v[k] = use_scale ? f.mul_plain(t, scale) : t;
+            }
+            u32x4 zz;
+            __builtin_memcpy(&zz, &z, 16);
+            if (NTT_PW_NT & 2) __builtin_nontemporal_store(zz, pc + i + u * stride);
+            else pc[i + u * stride] = zz;
+        }
+    }
+    for (; i < nchunks; i += stride) {
         Ch x = reinterpret_cast<const Ch *>(a)[i];
         Ch y = reinterpret_cast<const Ch *>(b)[i];
         Ch z;
