@@ -55,7 +55,7 @@ def test_multi_pass_planner_splits(oracle, wb, p, g):
 
 
 @pytest.mark.parametrize("ov", [(8, 4), (8, 5), (7, 6), (8, 7), (8, 8), (9, 4), (10, 4), (11, 5), (12, 4), (5, 4), (4, 6), (5, 6), (6, 7),
-                                (5, 5, 8), (13,), (13, 4)])
+                                (5, 5, 8), (13,), (13, 4), (7, 8), (9, 6), (10, 6)])
 def test_every_tile_shape(oracle, ov):
     logn = sum(ov)
     for wb, p, g in FIELDS[:2]:
