@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Bank model of the LDS access patterns of a radix-8 CONTIG tile of 8-byte words (ds_read/write_b64: two groups of 32 lanes, bank = word mod 32;
+b128: the four 16-lane groups of MI355X_MICROARCH.md, bank group = chunk mod 16) under paddings lin + a*(lin >> s1) + b*(lin >> s2): cycles per
+thread-iteration for the round-0 reads, the exchanges and the linear copy; brute force over two-level paddings (source of PassCfg::PAD64)."""
+# LDS bank-conflict model for the radix-8 (E=8, 8-byte words) CONTIG tile, padded lds_index(lin) = lin + (lin >> PS) * 2 (words)
+import itertools, collections
+GROUPS128 = [[0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27],[4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31],
+             [32,33,34,35,44,45,46,47,52,53,54,55,56,57,58,59],[36,37,38,39,40,41,42,43,48,49,50,51,60,61,62,63]]
+def idx(lin, PS): return lin + (lin >> PS) * 2 if PS else lin
+def cyc_b64(words):  # words per lane (64 lanes): two groups of 32; bank of an 8-byte word = (2*w) mod 64 -> w mod 32
+    tot = 0
+    for g in (range(0, 32), range(32, 64)):
+        c = collections.Counter(words[l] % 32 for l in g)
+        tot += max(c.values())
+    return tot
+def cyc_b128(chunks):  # 16-byte chunk index per lane; 4 groups of 16 lanes; chunk occupies 4 banks: chunk mod 16
+    tot = 0
+    for g in GROUPS128:
+        c = collections.Counter(chunks[l] % 16 for l in g)
+        tot += max(c.values())
+    return tot
+def model(LOG_M, NT, PS):
+    E, LOG_E = 8, 3
+    LOG_Q = LOG_M - LOG_E
+    R = (LOG_M + 2) // 3
+    win = [min(r * 3, LOG_M - 3) for r in range(R)]
+    res = {}
+    for r in range(R):
+        b0 = win[r]
+        tot = 0
+        for e in range(E):
+            words = []
+            for tid in range(64):  # first wave
+                q = tid & ((1 << LOG_Q) - 1); u = tid >> LOG_Q
+                q_lo, q_hi = q & ((1 << b0) - 1), q >> b0
+                lin = (u << LOG_M) | (q_hi << (b0 + 3)) | (e << b0) | q_lo
+                words.append(idx(lin, PS))
+            tot += cyc_b64(words)
+        res["round%d_b64x8" % r] = tot  # ideal: 8 instr x 2 cycles = 16
+    # round 0 as 4 x b128 (thread-contiguous words)
+    tot = 0
+    for j in range(4):
+        chunks = []
+        for tid in range(64):
+            lin = tid * 8 + 2 * j
+            chunks.append(idx(lin, PS) // 2)
+        tot += cyc_b128(chunks)
+    res["round0_b128x4"] = tot  # ideal 4 x 4 = 16
+    # linear copy: lane l, iteration i: chunk at wbase + i*128 + 2*l words
+    tot = 0
+    for i in range(4):
+        chunks = [idx(i * 128 + 2 * l, PS) // 2 for l in range(64)]
+        tot += cyc_b128(chunks)
+    res["linear_b128x4"] = tot
+    return res
+for LOG_M in (8, 9, 12):
+    for PS in (0, 3, 4, 5, 6):
+        print(LOG_M, "PS", PS, model(LOG_M, 256, PS))
+
+print("---- two-level paddings, LOG_M = 8 and 12: total cycles of (linear b128 + r0 b128 x2 + exchanges r1, r2 (,r3) read+write) ----")
+def idx2(lin, a, s1, b, s2): return lin + a * (lin >> s1) + b * (lin >> s2)
+def model2(LOG_M, a, s1, b, s2):
+    global idx
+    old = idx
+    idx = lambda lin, PS: idx2(lin, a, s1, b, s2)
+    r = model(LOG_M, 256, 1)
+    idx = old
+    R = (LOG_M + 2) // 3
+    tot = r["linear_b128x4"] + 2 * r["round0_b128x4"] + sum(2 * r["round%d_b64x8" % k] for k in range(1, R))
+    return tot, r
+best = []
+for a in (0, 2, 4, 6):
+    for s1 in (3, 4, 5):
+        for b in (0, 2, 4, 6):
+            for s2 in (5, 6, 7, 8, 9):
+                if s2 <= s1 or (a == 0 and b == 0): continue
+                t8, r8 = model2(8, a, s1, b, s2)
+                t12, r12 = model2(12, a, s1, b, s2)
+                best.append((t8 + t12, t8, t12, a, s1, b, s2))
+best.sort()
+ideal8 = 16 + 2 * 16 + 2 * 2 * 16; ideal12 = 16 + 2 * 16 + 3 * 2 * 16
+print("ideal", ideal8, ideal12, "current PS=3:", model2(8, 2, 3, 0, 9)[0], model2(12, 2, 3, 0, 9)[0])
+for row in best[:12]: print(row)
