@@ -106,9 +106,30 @@ int ntt_plan_generate_twiddles(ntt_plan_t plan, int kind, uint64_t g);
 int ntt_plan_get_twiddles(ntt_plan_t plan, int inverse, void *host_T);
 
 /* plan introspection (for harnesses): 0 logn, 1 word_bytes, 2 device,
- * 3 number of HBM passes of one forward transform, 4 has-inverse-table,
- * 32 + i: stages in pass i, 64 + i: first stage of pass i (pass 0 is the contiguous one) */
+ * 3 number of HBM passes of one forward transform (default decomposition), 4 has-inverse-table,
+ * 32 + i: stages in pass i, 64 + i: first stage of pass i (pass 0 is the contiguous one);
+ * 6 number of decomposition alternatives, 7 forced alternative (-1 = chosen by batch),
+ * 256 + 16*a + k for alternative a: k = 0 number of passes, k = 1..7 stages in pass k-1,
+ * k = 8..14 first stage of pass k-8, k = 15 the smallest batch this alternative is chosen for */
 int64_t ntt_plan_info(ntt_plan_t plan, int what);
+
+/* The stage decomposition into HBM passes is chosen at LAUNCH, by batch size, among alternatives fixed at plan creation
+ * from (N, word size, modulus class) -- the role of the reference's slab-size rule, where the per-tile slab follows from
+ * N and the number of cores (src/aie2.py:21-28).  The tables are decomposition-agnostic, so alternatives cost no device
+ * memory and every alternative computes the same words.
+ *   ntt_plan_select: the alternative ntt_forward / ntt_inverse / ntt_polymul_negacyclic run for `batch` (>= 0).
+ *   ntt_plan_set_policy: alternative = -1 (default) chooses by batch; k >= 0 pins alternative k.  Plan configuration, like
+ *   ntt_plan_set_twiddles: call it before the plan is shared between host threads. */
+int ntt_plan_select(ntt_plan_t plan, size_t batch);
+int ntt_plan_set_policy(ntt_plan_t plan, int alternative);
+
+/* A copy of `src` on another device (or the same one): tables are copied device-to-device (hipMemcpyPeer over xGMI, no
+ * host round trip, no host table needed -- works after ntt_plan_generate_twiddles too).  This is the multi-device leg of
+ * the boundary: the reference broadcasts its one table to every tile below the host (src/aie2.py:96-104, object-fifo
+ * broadcast of the root buffer) and scatters / gathers the data per tile (src/aie2.py:83-115); a host shards [B][N]
+ * over ntt_device_count() devices by cloning one plan per device and launching each shard on its own stream
+ * (tests/cxx/multi_device_host.cpp). */
+int ntt_plan_clone(ntt_plan_t src, int device, ntt_plan_t *out);
 
 /* ---- transforms ------------------------------------------------------------
  * Forward = the reference network (src/test.cpp:34-60; tile kernels

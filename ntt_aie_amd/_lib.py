@@ -9,8 +9,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# NTT_HIP_LIB: A/B experiments load another build of the same library (tools/README.md)
-LIB_PATH = os.environ.get("NTT_HIP_LIB") or os.path.join(_HERE, "libntt_hip.so")
+# The package reads NO environment variable (include/ntt_hip.h promises that no variable can change a result; the C
+# library itself reads only NTT_ROCTX, which switches profiling ranges).  Experiments that want another build of the
+# library say so in code: tools/_explib.py calls use_library(path, allow_experiment=True) before the first transform.
+LIB_PATH = os.path.join(_HERE, "libntt_hip.so")
+_allow_experiment = False
 
 # error codes of include/ntt_hip.h
 NTT_OK = 0
@@ -29,7 +32,7 @@ LAYOUT_AIE_BLOCK16 = 1
 # every symbol include/ntt_hip.h declares
 EXPORTS = (
     "ntt_version", "ntt_error_string", "ntt_device_count", "ntt_plan_create", "ntt_plan_destroy",
-    "ntt_plan_set_twiddles", "ntt_make_roots", "ntt_make_table", "ntt_plan_generate_twiddles", "ntt_plan_get_twiddles", "ntt_plan_info", "ntt_forward",
+    "ntt_plan_set_twiddles", "ntt_make_roots", "ntt_make_table", "ntt_plan_generate_twiddles", "ntt_plan_get_twiddles", "ntt_plan_info", "ntt_plan_select", "ntt_plan_set_policy", "ntt_plan_clone", "ntt_forward",
     "ntt_forward_profile", "ntt_inverse", "ntt_pointwise_mul", "ntt_polymul_negacyclic", "ntt_count_noncanonical", "ntt_forward_stages",
 )
 
@@ -68,6 +71,9 @@ def open_library(path: str) -> C.CDLL:
     L.ntt_plan_get_twiddles.argtypes = [vp, C.c_int, vp]
     L.ntt_plan_info.restype = C.c_int64
     L.ntt_plan_info.argtypes = [vp, C.c_int]
+    L.ntt_plan_select.argtypes = [vp, sz]
+    L.ntt_plan_set_policy.argtypes = [vp, C.c_int]
+    L.ntt_plan_clone.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.ntt_forward.argtypes = [vp, vp, vp, sz, C.c_int, vp]
     L.ntt_forward_profile.argtypes = [vp, vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float), C.c_int,
                                       C.POINTER(C.c_int)]
@@ -89,6 +95,25 @@ class NTTError(RuntimeError):
 _lib = None
 
 
+def is_experiment_build(L: C.CDLL) -> bool:
+    """libntt_hip_exp.so (-DNTT_EXPERIMENT: debug switches that redirect loads / skip stores) exports ntt_plan_set_debug;
+    the product library does not."""
+    try:
+        L.ntt_plan_set_debug
+    except AttributeError:
+        return False
+    return True
+
+
+def use_library(path: str, allow_experiment: bool = False) -> None:
+    """Select another build of the C-ABI for this process (tools/ A/B experiments).  Must run before the first lib() call."""
+    global LIB_PATH, _allow_experiment
+    if _lib is not None:
+        raise RuntimeError("use_library() after the library was loaded (%s)" % LIB_PATH)
+    LIB_PATH = os.path.abspath(path)
+    _allow_experiment = bool(allow_experiment)
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -105,6 +130,9 @@ def lib() -> C.CDLL:
         except ImportError:
             pass
         L = open_library(LIB_PATH)
+        if is_experiment_build(L) and not _allow_experiment:
+            raise ImportError("%s is an experiment build (-DNTT_EXPERIMENT: its debug switches can skip stores); the product "
+                              "path refuses it -- tools select it with use_library(path, allow_experiment=True)" % LIB_PATH)
         _lib = L
     return _lib
 

@@ -12,6 +12,7 @@ struct ErasedArgs {
     const void *in;
     void *out;
     const void *tw;
+    const void *tw_sc;     // scaled inverse, Goldilocks CONTIG pass: stage-0 twiddles * N^-1 (PassArgs::tw_sc); null = phase_scale
     uint32_t p, pinv, r2;  // FieldM32 parameters (ignored by FieldGL)
     int n, s0;
     uint32_t batch;
@@ -38,6 +39,9 @@ hipError_t launch_m32_inv(bool contig, int log_m, const ErasedArgs &a, hipStream
 // hipErrorInvalidValue when this (word size, log_m) has no fused kernel (callers then run the separate passes).
 hipError_t launch_gl_product_mid(int log_m, const ErasedArgs &a, hipStream_t s);
 bool have_gl_product_mid(int log_m);   // Goldilocks: unit sizes 2^7 .. 2^12
+// one grid covers the batch (blockIdx.y range) -- computed by the launcher's own geometry call
+bool gl_product_mid_fits(int log_m, int n, uint32_t batch, uint32_t target_wgs);
+bool m32_product_mid_fits(int log_m, int n, uint32_t batch, uint32_t target_wgs);
 hipError_t launch_m32_product_mid(int log_m, const ErasedArgs &a, hipStream_t s);
 bool have_m32_product_mid(int log_m);  // 4-byte words: unit sizes 2^6 .. 2^13
 
@@ -61,6 +65,9 @@ hipError_t launch_pointwise_m32(const void *a, const void *b, void *c, size_t co
 hipError_t launch_gen_table_gl(void *T, int logn, int kind, uint64_t base_m, uint64_t one_m, hipStream_t s);
 hipError_t launch_gen_table_m32(void *T, int logn, int kind, uint32_t base_m, uint32_t one_m, uint32_t p,
                                 uint32_t pinv, uint32_t r2, hipStream_t s);
+
+// out[i] = T[i] * c (table form both): the N/2 scaled stage-0 twiddles of the Goldilocks inverse transform
+hipError_t launch_scale_table_gl(const void *T, void *out, size_t count, uint64_t c_m, hipStream_t s);
 
 // number of words >= p in a buffer (precondition check); d_out = one zeroed 64-bit device word
 hipError_t launch_count_noncanonical(const void *a, size_t count, int word_bytes, uint64_t p, void *d_out, hipStream_t s);

@@ -8,6 +8,20 @@ namespace ntt {
 // against 1.4 ms for the three separate launches, whose small units are staged through LDS -- tools/polymul_small.py)
 bool have_m32_product_mid(int log_m) { return log_m >= 6 && log_m <= 13; }
 
+bool m32_product_mid_fits(int log_m, int n, uint32_t batch, uint32_t target_wgs) {
+    switch (log_m) {
+        case 6: return product_fits<ProductCfgM32<6>>(n, batch, target_wgs);
+        case 7: return product_fits<ProductCfgM32<7>>(n, batch, target_wgs);
+        case 8: return product_fits<ProductCfgM32<8>>(n, batch, target_wgs);
+        case 9: return product_fits<ProductCfgM32<9>>(n, batch, target_wgs);
+        case 10: return product_fits<ProductCfgM32<10>>(n, batch, target_wgs);
+        case 11: return product_fits<ProductCfgM32<11>>(n, batch, target_wgs);
+        case 12: return product_fits<ProductCfgM32<12>>(n, batch, target_wgs);
+        case 13: return product_fits<ProductCfgM32<13>>(n, batch, target_wgs);
+        default: return false;
+    }
+}
+
 hipError_t launch_m32_product_mid(int log_m, const ErasedArgs &a, hipStream_t s) {
     switch (log_m) {
         case 5: return launch_product<ProductCfgM32<5>>(a, s);

@@ -136,6 +136,14 @@ __global__ __launch_bounds__(256) void gen_table_kernel(typename F::W *T, int lo
     }
 }
 
+// out[i] = T[i] * c, both in table (Montgomery) form: the scaled stage-0 twiddles of the inverse transform (pass.h: fold_scale)
+template <class F>
+__global__ __launch_bounds__(256) void scale_table_kernel(const typename F::W *T, typename F::W *out, size_t count,
+                                                          typename F::W c_m, F f) {
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t) gridDim.x * blockDim.x)
+        out[i] = f.mul(T[i], c_m);
+}
+
 // precondition check: number of words >= p (the kernels, like the reference's vector_modadd /
 // vector_modsub, src/aie_core.cc:41-62, assume canonical residues)
 template <class W>
@@ -184,6 +192,13 @@ hipError_t launch_gen_table_m32(void *T, int logn, int kind, uint32_t base_m, ui
                                 uint32_t pinv, uint32_t r2, hipStream_t s) {
     hipLaunchKernelGGL(gen_table_kernel<FieldM32>, dim3(grid_for((size_t) 1 << logn)), dim3(256), 0, s,
                        (uint32_t *) T, logn, kind, base_m, one_m, FieldM32{p, pinv, r2});
+    return hipGetLastError();
+}
+
+hipError_t launch_scale_table_gl(const void *T, void *out, size_t count, uint64_t c_m, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(scale_table_kernel<FieldGL>, dim3(grid_for(count)), dim3(256), 0, s, (const uint64_t *) T,
+                       (uint64_t *) out, count, c_m, FieldGL{});
     return hipGetLastError();
 }
 

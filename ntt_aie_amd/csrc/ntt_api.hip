@@ -85,6 +85,7 @@ struct ntt_plan {
     // device tables, table form
     void *d_tw_fwd;
     void *d_tw_inv;
+    void *d_tw_inv_sc;  // 8-byte words: T^-1[N/2 + i] * N^-1, i < N/2 (stage-0 twiddles of the scaled inverse, pass.h: fold_scale)
     bool has_table, has_inv;
     uint64_t scale_tf;     // N^-1 in table form
     uint64_t ninv_plain;   // N^-1 plain
@@ -97,12 +98,21 @@ struct ntt_plan {
     size_t fused_max_batch;
     unsigned long long *d_counter;  // one device word for ntt_count_noncanonical (no allocation per call)
     std::mutex counter_mu;          // ... which is the only entry point that writes plan-owned state after creation
-    std::vector<PassDesc> passes;
+    std::vector<PassDesc> passes;  // = alts[0].passes: the default decomposition (ntt_plan_info 3 / 32+ / 64+)
+    std::vector<PlanAlt> alts;     // launch-time alternatives, ascending min_batch (plan.h: plan_alternatives)
+    int forced_alt;                // ntt_plan_set_policy: -1 = by batch, k >= 0 = always alternative k
 };
 
 namespace {
 
 size_t table_bytes(const ntt_plan *pl) { return ((size_t) 1 << pl->logn) * pl->word_bytes; }
+size_t sc_table_bytes(const ntt_plan *pl) { return pl->word_bytes == 8 ? table_bytes(pl) / 2 : 0; }
+
+// the decomposition the launchers run for this batch
+const std::vector<PassDesc> &passes_for(const ntt_plan *pl, size_t batch) {
+    const int k = pl->forced_alt >= 0 ? pl->forced_alt : select_alternative(pl->alts, batch);
+    return pl->alts[(size_t) k].passes;
+}
 
 ntt::ErasedArgs base_args(const ntt_plan *pl, const PassDesc &pd, const void *in, void *out, size_t batch) {
     ntt::ErasedArgs a;
@@ -148,14 +158,15 @@ int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
         if (pl->dbg & (16 | 32 | 64)) return NTT_OK;  // timing experiments: fused launch alone
     }
 #endif
-    for (const PassDesc &pd : pl->passes) {
+    const std::vector<PassDesc> &passes = passes_for(pl, batch);
+    for (const PassDesc &pd : passes) {
 #if defined(NTT_EXPERIMENT)
-        if (pl->only_pass >= 0 && (int) (&pd - &pl->passes.front()) != pl->only_pass) continue;  // timing experiment: outputs meaningless
+        if (pl->only_pass >= 0 && (int) (&pd - &passes.front()) != pl->only_pass) continue;  // timing experiment: outputs meaningless
 #endif
         RoctxRange pass("fwd pass", pd.contig, pd.s0, pd.log_m);
         ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
         a.skip_if = skip_if;
-        if (&pd == &pl->passes.front() && in2) {  // first pass only (d_out may alias d_in)
+        if (&pd == &passes.front() && in2) {  // first pass only (d_out may alias d_in)
             a.in2 = in2;
             a.pw_scale = to_table_form(to_table_form(pw_scale_plain % pl->p, pl->p, pl->word_bytes), pl->p, pl->word_bytes);
         }
@@ -173,14 +184,17 @@ int run_inverse(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
                 hipStream_t s) {
     RoctxRange whole("ntt_inverse");
     const void *src = d_in;
-    for (size_t i = pl->passes.size(); i-- > 0;) {
-        const PassDesc &pd = pl->passes[i];
+    const std::vector<PassDesc> &passes = passes_for(pl, batch);
+    for (size_t i = passes.size(); i-- > 0;) {
+        const PassDesc &pd = passes[i];
         RoctxRange pass("inv pass", pd.contig, pd.s0, pd.log_m);
         ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
         a.tw = pl->d_tw_inv;
         a.layout = layout;
         a.do_scale = (scale && i == 0) ? 1 : 0;
         a.scale = pl->scale_tf;
+        // Goldilocks: N^-1 rides on the last executed stage (stage 0 of the CONTIG pass) instead of a sweep over the outputs
+        a.tw_sc = a.do_scale ? pl->d_tw_inv_sc : nullptr;
         hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_inv(pd.contig, pd.log_m, a, s)
                                            : ntt::launch_m32_inv(pd.contig, pd.log_m, a, s);
         if (e != hipSuccess) return (int) e;
@@ -193,7 +207,18 @@ int run_inverse(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
 
 extern "C" {
 
-int ntt_version(void) { return 200; /* 0.2.0 */ }
+int ntt_version(void) { return 300; /* 0.3.0 */ }
+
+#if defined(NTT_EXPERIMENT)
+// libntt_hip_exp.so only (never declared in include/ntt_hip.h, never exported by the product): the timing switches of
+// PassArgs::dbg for ONE plan, set explicitly instead of through the process environment (bench.py's VALU-floor leg).
+// The symbol doubles as the build's identity: ntt_aie_amd/_lib.py refuses a library that exports it.
+int ntt_plan_set_debug(ntt_plan_t pl, int flags) {
+    if (!pl) return NTT_E_ARG;
+    pl->dbg = flags;
+    return NTT_OK;
+}
+#endif
 
 const char *ntt_error_string(int code) {
     switch (code) {
@@ -236,7 +261,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     pl->p = p;
     pl->word_bytes = word_bytes;
     pl->device = device;
-    pl->d_tw_fwd = pl->d_tw_inv = nullptr;
+    pl->d_tw_fwd = pl->d_tw_inv = pl->d_tw_inv_sc = nullptr;
     pl->has_table = pl->has_inv = false;
     pl->pinv = pl->r2 = 0;
     if (word_bytes == 4) {
@@ -254,7 +279,9 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     pl->d_fused_ctl = nullptr;
     pl->fused_max_batch = 0;
     pl->d_counter = nullptr;
-    pl->passes = plan_passes(logn, word_bytes);
+    pl->alts = plan_alternatives(logn, word_bytes, p);
+    pl->passes = pl->alts[0].passes;
+    pl->forced_alt = -1;
 #if defined(NTT_EXPERIMENT)
     // Experiment knobs exist only in libntt_hip_exp.so (make exp; tools/): the product library reads NO environment
     // variable, so a stray NTT_DEBUG_FLAGS in a user's shell cannot redirect loads and stores.
@@ -277,14 +304,17 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
             char *end = nullptr;
             const long m = strtol(c, &end, 10);
             if (end == c) break;
-            if (v.empty()) ok = m >= 1 && m <= 13;
-            else ok = m >= MIN_COL_LOG_M && m <= MAX_COL_LOG_M;
+            if (v.empty()) ok = m >= 1 && m <= (word_bytes == 4 ? 14 : 13);
+            else ok = m >= MIN_COL_LOG_M && m <= MAX_COL_LOG_M_WIDE;
             v.push_back({v.empty(), s0, (int) m});
             s0 += (int) m;
             c = *end == ',' ? end + 1 : end;
         }
         if (v.size() > 1 && v[0].log_m < ntt::col_log_c(word_bytes)) ok = false;  // column tiles are 2^log_c words wide
-        if (ok && s0 == logn && !v.empty()) pl->passes = v;  // anything else: keep the default split
+        if (ok && s0 == logn && !v.empty()) {  // anything else: keep the planner's alternatives
+            pl->passes = v;
+            pl->alts.assign(1, PlanAlt{v, 0});
+        }
     }
 #endif
     DeviceGuard g(device);
@@ -294,6 +324,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     }
     hipError_t e = hipMalloc(&pl->d_tw_fwd, table_bytes(pl));
     if (e == hipSuccess) e = hipMalloc(&pl->d_tw_inv, table_bytes(pl));
+    if (e == hipSuccess && sc_table_bytes(pl)) e = hipMalloc(&pl->d_tw_inv_sc, sc_table_bytes(pl));
     if (e == hipSuccess) e = hipMalloc(&pl->d_counter, sizeof(*pl->d_counter));
 #if defined(NTT_EXPERIMENT)
     if (e == hipSuccess && pl->fused && logn == 16 && word_bytes == 8) {
@@ -304,6 +335,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     if (e != hipSuccess) {
         if (pl->d_tw_fwd) (void) hipFree(pl->d_tw_fwd);
         if (pl->d_tw_inv) (void) hipFree(pl->d_tw_inv);
+        if (pl->d_tw_inv_sc) (void) hipFree(pl->d_tw_inv_sc);
         if (pl->d_counter) (void) hipFree(pl->d_counter);
         delete pl;
         return (int) e;
@@ -317,6 +349,7 @@ int ntt_plan_destroy(ntt_plan_t pl) {
     DeviceGuard g(pl->device);
     if (pl->d_tw_fwd) (void) hipFree(pl->d_tw_fwd);
     if (pl->d_tw_inv) (void) hipFree(pl->d_tw_inv);
+    if (pl->d_tw_inv_sc) (void) hipFree(pl->d_tw_inv_sc);
     if (pl->d_fused_ctl) (void) hipFree(pl->d_fused_ctl);
     if (pl->d_counter) (void) hipFree(pl->d_counter);
     delete pl;
@@ -350,6 +383,11 @@ int ntt_plan_set_twiddles(ntt_plan_t pl, const void *host_T) {
     if (g.err != hipSuccess) return (int) g.err;
     hipError_t e = hipMemcpy(pl->d_tw_fwd, buf_f.data(), buf_f.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(pl->d_tw_inv, buf_i.data(), buf_i.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && pl->d_tw_inv_sc && inv_ok) {
+        std::vector<uint64_t> sc(N / 2);
+        for (size_t i = 0; i < N / 2; i++) sc[i] = to_table_form(mulmod(Ti[N / 2 + i], pl->ninv_plain, p), p, 8);
+        e = hipMemcpy(pl->d_tw_inv_sc, sc.data(), sc.size() * sizeof(uint64_t), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) return (int) e;
     pl->has_table = true;
     pl->has_inv = inv_ok;
@@ -391,6 +429,8 @@ int ntt_plan_generate_twiddles(ntt_plan_t pl, int kind, uint64_t g) {
         e = ntt::launch_gen_table_gl(pl->d_tw_fwd, pl->logn, kind, to_table_form(base, p, 8), one_m, nullptr);
         if (e == hipSuccess)
             e = ntt::launch_gen_table_gl(pl->d_tw_inv, pl->logn, kind, to_table_form(base_inv, p, 8), one_m, nullptr);
+        if (e == hipSuccess)  // stage-0 twiddles of the scaled inverse: T^-1[N/2 + i] * N^-1
+            e = ntt::launch_scale_table_gl((const uint64_t *) pl->d_tw_inv + N / 2, pl->d_tw_inv_sc, N / 2, pl->scale_tf, nullptr);
     } else {
         e = ntt::launch_gen_table_m32(pl->d_tw_fwd, pl->logn, kind, (uint32_t) to_table_form(base, p, 4),
                                       (uint32_t) one_m, (uint32_t) p, pl->pinv, pl->r2, nullptr);
@@ -435,7 +475,17 @@ int64_t ntt_plan_info(ntt_plan_t pl, int what) {
         case 3: return (int64_t) pl->passes.size();
         case 4: return pl->has_inv ? 1 : 0;
         case 5: return pl->d_fused_ctl ? 1 : 0;
+        case 6: return (int64_t) pl->alts.size();
+        case 7: return pl->forced_alt;
         default: break;
+    }
+    if (what >= 256 && what < 256 + 16 * (int) pl->alts.size()) {
+        const PlanAlt &alt = pl->alts[(size_t) (what - 256) / 16];
+        const int k = (what - 256) % 16;
+        if (k == 0) return (int64_t) alt.passes.size();
+        if (k >= 1 && k <= 7) return k - 1 < (int) alt.passes.size() ? alt.passes[(size_t) k - 1].log_m : NTT_E_ARG;
+        if (k >= 8 && k <= 14) return k - 8 < (int) alt.passes.size() ? alt.passes[(size_t) k - 8].s0 : NTT_E_ARG;
+        return (int64_t) alt.min_batch;  // k == 15
     }
     if (what >= 32 && what < 32 + (int) pl->passes.size()) return pl->passes[what - 32].log_m;
     if (what >= 64 && what < 64 + (int) pl->passes.size()) return pl->passes[what - 64].s0;
@@ -449,6 +499,56 @@ int64_t ntt_plan_info(ntt_plan_t pl, int what) {
     }
 #endif
     return NTT_E_ARG;
+}
+
+int ntt_plan_select(ntt_plan_t pl, size_t batch) {
+    if (!pl) return NTT_E_ARG;
+    return pl->forced_alt >= 0 ? pl->forced_alt : select_alternative(pl->alts, batch);
+}
+
+int ntt_plan_set_policy(ntt_plan_t pl, int alternative) {
+    if (!pl || alternative < -1 || alternative >= (int) pl->alts.size()) return NTT_E_ARG;
+    pl->forced_alt = alternative;
+    return NTT_OK;
+}
+
+int ntt_plan_clone(ntt_plan_t src, int device, ntt_plan_t *out) {
+    if (!out) return NTT_E_ARG;
+    *out = nullptr;
+    if (!src) return NTT_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return NTT_E_NODEVICE;
+    ntt_plan_t pl = nullptr;
+    int rc = ntt_plan_create(&pl, src->logn, src->p, src->word_bytes, device);
+    if (rc != NTT_OK) return rc;
+    pl->alts = src->alts;  // an experiment split or a forced policy travels with the plan
+    pl->passes = src->passes;
+    pl->forced_alt = src->forced_alt;
+    pl->target_wgs = src->target_wgs;
+    pl->target_wgs_col = src->target_wgs_col;
+    if (src->has_table) {
+        // device-to-device, no host copy of the table: over xGMI when the devices differ (hipMemcpyPeer), which is what the
+        // reference's on-chip table broadcast does below its host (src/aie2.py:96-104)
+        auto copy = [&](void *dst, const void *from, size_t bytes) -> hipError_t {
+            if (bytes == 0 || !dst || !from) return hipSuccess;
+            return device == src->device ? hipMemcpy(dst, from, bytes, hipMemcpyDeviceToDevice)
+                                         : hipMemcpyPeer(dst, device, from, src->device, bytes);
+        };
+        DeviceGuard g(device);
+        hipError_t e = g.err;
+        if (e == hipSuccess) e = copy(pl->d_tw_fwd, src->d_tw_fwd, table_bytes(src));
+        if (e == hipSuccess) e = copy(pl->d_tw_inv, src->d_tw_inv, table_bytes(src));
+        if (e == hipSuccess) e = copy(pl->d_tw_inv_sc, src->d_tw_inv_sc, sc_table_bytes(src));
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            (void) ntt_plan_destroy(pl);
+            return (int) e;
+        }
+        pl->has_table = true;
+        pl->has_inv = src->has_inv;
+    }
+    *out = pl;
+    return NTT_OK;
 }
 
 int ntt_forward(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int out_layout, void *stream) {
@@ -467,14 +567,16 @@ int ntt_forward_profile(ntt_plan_t pl, const void *d_in, void *d_out, size_t bat
                         void *stream, float *ms_per_pass, int max_passes, int *n_passes) {
     int rc = check_io(pl, d_in, d_out, batch);
     if (rc) return rc;
-    if (!ms_per_pass || !n_passes || max_passes < (int) pl->passes.size()) return NTT_E_ARG;
-    *n_passes = (int) pl->passes.size();
+    if (!ms_per_pass || !n_passes) return NTT_E_ARG;
+    const std::vector<PassDesc> &passes = passes_for(pl, batch);
+    if (max_passes < (int) passes.size()) return NTT_E_ARG;
+    *n_passes = (int) passes.size();
     if (!pl->has_table) return NTT_E_NOTABLE;
     if (batch == 0) return NTT_OK;
     DeviceGuard g(pl->device);
     if (g.err != hipSuccess) return (int) g.err;
     hipStream_t s = (hipStream_t) stream;
-    const size_t np = pl->passes.size();
+    const size_t np = passes.size();
     std::vector<hipEvent_t> ev;
     ev.reserve(np + 1);
     for (size_t i = 0; i <= np; i++) {
@@ -489,7 +591,7 @@ int ntt_forward_profile(ntt_plan_t pl, const void *d_in, void *d_out, size_t bat
     const void *src = d_in;
     hipError_t e = hipEventRecord(ev[0], s);
     for (size_t i = 0; i < np && e == hipSuccess; i++) {
-        const PassDesc &pd = pl->passes[i];
+        const PassDesc &pd = passes[i];
         ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
         a.tw = pl->d_tw_fwd;
         a.layout = out_layout;
@@ -550,26 +652,26 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
     // (SURVEY F6-ii), so  c = Fwd( InvU(a) . InvU(b) . N^-1 ).
     const size_t operand_bytes = (batch << pl->logn) * (size_t) pl->word_bytes;
     const bool contiguous = (const char *) d_b == (const char *) d_a + operand_bytes && 2 * batch <= 0x7FFFFFFFull;
-    const PassDesc &first = pl->passes.front();
+    const std::vector<PassDesc> &passes = passes_for(pl, batch);
+    const PassDesc &first = passes.front();
     // Goldilocks, first (or only) pass of 7..12 stages: the radix-8 product kernel exists for that unit size.  A single-pass
     // size (2^7 <= N <= 2^12) is then ONE launch for the whole product: read a, read b, write c.
-    // ... 4-byte words: radix-16 product kernel, unit sizes 2^5 .. 2^12 (any odd p: all three butterfly streams).
+    // ... 4-byte words: radix-16 product kernel, unit sizes 2^6 .. 2^13 (any odd p: all three butterfly streams).
     bool fused_mid = first.contig && (pl->word_bytes == 8 ? ntt::have_gl_product_mid(first.log_m)
                                                            : ntt::have_m32_product_mid(first.log_m));
     if (fused_mid) {
         // the product launch is not sliced: beyond blockIdx.y's range (tens of millions of tiny polynomials) take the
-        // separate passes, whose launcher slices the batch
-        const int log_u = pl->word_bytes == 8 ? ((first.log_m >= 10 ? 9 : 8) + 3 - first.log_m) : (12 - first.log_m);
-        const ntt::PassGeom g = ntt::pass_geometry(pl->logn, 0, first.log_m, 0, log_u, true, batch, pl->target_wgs);
-        if (g.grid_y > 65535u) fused_mid = false;
+        // separate passes, whose launcher slices the batch.  The check IS the launcher's geometry call (product_fits).
+        fused_mid = pl->word_bytes == 8 ? ntt::gl_product_mid_fits(first.log_m, pl->logn, (uint32_t) batch, pl->target_wgs)
+                                        : ntt::m32_product_mid_fits(first.log_m, pl->logn, (uint32_t) batch, pl->target_wgs);
     }
     if (fused_mid) {
         // The column passes (if any) of both unscaled inverse transforms, then ONE launch that runs
         // the last inverse pass of a and of b, the pointwise product * N^-1 and the first forward pass on each
         // 2^log_m-word unit while it is workgroup-resident (3 N words of HBM traffic instead of 7 N), then the
         // forward column passes.
-        for (size_t i = pl->passes.size(); i-- > 1;) {
-            const PassDesc &pd = pl->passes[i];
+        for (size_t i = passes.size(); i-- > 1;) {
+            const PassDesc &pd = passes[i];
             RoctxRange pass("product: inv pass", pd.contig, pd.s0, pd.log_m);
             for (int op = 0; op < (contiguous ? 1 : 2); op++) {
                 void *buf = op == 0 ? d_a : d_b;
@@ -593,8 +695,8 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
                                                : ntt::launch_m32_product_mid(first.log_m, a, s);
             if (e != hipSuccess) return (int) e;
         }
-        for (size_t i = 1; i < pl->passes.size(); i++) {
-            const PassDesc &pd = pl->passes[i];
+        for (size_t i = 1; i < passes.size(); i++) {
+            const PassDesc &pd = passes[i];
             RoctxRange pass("product: fwd pass", pd.contig, pd.s0, pd.log_m);
             ntt::ErasedArgs a = base_args(pl, pd, d_out, d_out, batch);
             a.tw = pl->d_tw_fwd;

@@ -238,7 +238,7 @@ template <class F, int LOG_M, bool INV>
 using ColPassCfg = std::conditional_t<
     NTT_COL_E8 && sizeof(typename F::W) == 8 && LOG_M == 8,
     PassCfg<F, LOG_M, 4, false, INV, 0xF, 3, 9>,
-    PassCfg<F, LOG_M, col_log_c(sizeof(typename F::W)), false, INV, 0xF, 4, col_log_nt(sizeof(typename F::W))>>;
+    PassCfg<F, LOG_M, col_log_c(sizeof(typename F::W)), false, INV, 0xF, 4, col_log_nt(sizeof(typename F::W)) + (LOG_M > 8 ? LOG_M - 8 : 0)>>;
 
 // How the rows of blockIdx.y share the polynomial groups of the batch.  Rows [0, rows[0]) stream `ppw` groups each through
 // their resident twiddles; the next rows[1] rows ppw/2 each, then ppw/4, then ppw/8 (0 rows = level absent).  Rows are
@@ -255,6 +255,8 @@ struct PassArgs {
     const W *in;
     W *out;
     const W *tw;  // device table for this direction (T or T^-1), table form
+    const W *tw_sc;  // inverse CONTIG pass with the N^-1 scaling folded into stage 0 (fold_scale<Cfg>()): the N/2 twiddles of
+                     // stage 0 times N^-1, tw_sc[i] = T^-1[N/2 + i] * N^-1 in table form; null = unfolded (phase_scale)
     typename Cfg::F field;
     int n;   // log2 N
     int s0;  // first stage of the pass
@@ -338,7 +340,20 @@ template <class Cfg, int r>
 constexpr bool tw_uniform() {
     // one unit per workgroup, outermost window: the twiddle index has no lane-dependent part,
     // so the table entries live in SGPRs (column passes of 8 stages, CONTIG passes of 12)
-    return Cfg::LOG_U == 0 && (Cfg::win(r) + Cfg::LOG_E >= Cfg::LOG_M) && sizeof(typename Cfg::W) == 8;
+    // ... or, in a column pass, a window that starts at or above the wave boundary: thread q sits at mid bits
+    // (q >> b0) << (b0 + LOG_E), and q >> b0 involves only workgroup-thread bits >= LOG_C + b0 >= 6, i.e. the wave number
+    // (the middle round of the 9-stage column pass: 512 rows, windows 0 / 4 / 5)
+    return Cfg::LOG_U == 0 && sizeof(typename Cfg::W) == 8 &&
+           ((Cfg::win(r) + Cfg::LOG_E >= Cfg::LOG_M) || (!Cfg::CONTIG && Cfg::win(r) + Cfg::LOG_C >= 6));
+}
+
+// N^-1 folded into the LAST executed stage of the scaled inverse transform (stage 0, in the CONTIG pass):
+//   (u, v) -> (u*c + v*(T^-1*c), u*c - v*(T^-1*c)),  c = N^-1
+// costs one extra product per butterfly of that stage (N/2 per transform) where a scaling sweep over the outputs costs N;
+// T^-1*c is a plan-time table of N/2 words (PassArgs::tw_sc).  Goldilocks only (the 4-byte streams keep phase_scale).
+template <class Cfg>
+constexpr bool fold_scale() {
+    return Cfg::INV && Cfg::CONTIG && std::is_same<typename Cfg::F, FieldGL>::value;
 }
 
 // ---- host index model only: LDS hazard tracking -----------------------------------------
@@ -375,8 +390,15 @@ NTT_HD void load_twiddles(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
         constexpr int cnt = Cfg::E >> (t + 1);
         constexpr int off = Cfg::E - (Cfg::E >> t);
         const int s = a.s0 + m;
-        const uint32_t base = (1u << (a.n - s - 1)) + (c.hi << (Cfg::LOG_M - m - 1)) +
-                              (q_hi << (Cfg::LOG_E - t - 1));
+        uint32_t base = (1u << (a.n - s - 1)) + (c.hi << (Cfg::LOG_M - m - 1)) +
+                        (q_hi << (Cfg::LOG_E - t - 1));
+        const typename Cfg::W *tab = a.tw;
+        if constexpr (fold_scale<Cfg>() && m == 0) {
+            if (a.tw_sc != nullptr) {  // uniform: the launcher sets it together with the SC kernel (s0 == 0: stage 0)
+                tab = a.tw_sc;
+                base -= 1u << (a.n - 1);
+            }
+        }
         // the cnt entries of a stage are consecutive and `base` is a multiple of cnt (every term is a multiple of
         // 2^(LOG_E-t-1)): fetch them in 16-byte pieces where there are that many (5 requests per round instead of 15)
         constexpr int TV = cnt * (int) sizeof(typename Cfg::W) >= 16 ? 16 / (int) sizeof(typename Cfg::W) : cnt;
@@ -384,11 +406,11 @@ NTT_HD void load_twiddles(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
 #pragma unroll
         for (int k = 0; k < cnt; k += TV) {
 #if defined(__HIP_DEVICE_COMPILE__)
-            const Chunk<typename Cfg::W, TV> ch = *reinterpret_cast<const Chunk<typename Cfg::W, TV> *>(a.tw + base + k);
+            const Chunk<typename Cfg::W, TV> ch = *reinterpret_cast<const Chunk<typename Cfg::W, TV> *>(tab + base + k);
 #pragma unroll
             for (int i = 0; i < TV; ++i) tv[k + i] = ch.v[i];
 #else
-            for (int i = 0; i < TV; ++i) tv[k + i] = a.tw[base + k + i];
+            for (int i = 0; i < TV; ++i) tv[k + i] = tab[base + k + i];
 #endif
         }
 #pragma unroll
@@ -424,9 +446,11 @@ NTT_HD void phase_init(Ctx<Cfg> &c, const PassArgs<Cfg> &a, uint32_t tid, uint32
     {
         uint32_t y = by, base = 0;
         int p = a.ppw;
+        // an all-zero Taper (a launcher that filled in ppw only) means "no taper": every row streams ppw groups
+        const bool tapered = (a.tp.rows[0] | a.tp.rows[1] | a.tp.rows[2] | a.tp.rows[3]) != 0u;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            if (y < a.tp.rows[k]) break;
+            if (!tapered || y < a.tp.rows[k]) break;
             base += a.tp.rows[k] * (uint32_t) p;
             y -= a.tp.rows[k];
             p >>= 1;
@@ -867,8 +891,10 @@ NTT_HD void phase_lds_write(Ctx<Cfg> &c, typename Cfg::W *lds, bool perm = false
 // the kernel argument.  The GPU kernels decide ONCE, around the whole pass (pass_kernel.inc): a branch per asm
 // statement made hipcc reconcile the register assignment of the three arms with ~250 v_mov per polynomial.
 // TW_READY: the caller has already put this round's twiddles into c.tw[r] (run_product_pass reads them from an LDS table)
-template <class Cfg, int r, int M32_MODE = -1, bool TW_READY = false>
+// SC: the N^-1 scaling is folded into stage 0 (fold_scale<Cfg>(); c.tw[0] then holds T^-1 * N^-1 for that stage)
+template <class Cfg, int r, int M32_MODE = -1, bool TW_READY = false, bool SC = false>
 NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
+    static_assert(!SC || fold_scale<Cfg>(), "folded scaling: Goldilocks inverse CONTIG passes only");
     using W = typename Cfg::W;
     constexpr int b0 = Cfg::win(r);
     constexpr int lo = Cfg::stage_lo(r), hi = Cfg::stage_hi(r);
@@ -913,6 +939,10 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
                 constexpr int eA = ((k0 >> t) << (t + 1)) | (k0 & ((1 << t) - 1));
                 constexpr int eB = ((k1 >> t) << (t + 1)) | (k1 & ((1 << t) - 1));
                 const W TA = c.tw[r][off + (eA >> (t + 1))], TB = c.tw[r][off + (eB >> (t + 1))];
+                if constexpr (SC && m == 0) {  // last executed stage, scaling folded in (stage-0 twiddles differ per thread: "v" forms)
+                    if constexpr (Cfg::LOG_E < 4) gl_invs2_v_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, a.scale);
+                    else gl_invs2_v(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, a.scale);
+                } else
                 if constexpr (!Cfg::CONTIG && Cfg::LOG_E < 4) {  // experimental light column kernel: scratch at v[56:79]
                     if constexpr (tw_uniform<Cfg, r>()) {
                         if constexpr (!Cfg::INV) gl_fwd2_s_lo2(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
@@ -947,6 +977,10 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
             if constexpr (!Cfg::INV) {
                 c.x[e] = f.add(x, y);
                 c.x[e1] = f.mul(f.sub(x, y), T);
+            } else if constexpr (SC && m == 0) {
+                const W w = f.mul(y, T), u = f.mul(x, a.scale);  // T = T^-1 * N^-1 here
+                c.x[e] = f.add(u, w);
+                c.x[e1] = f.sub(u, w);
             } else {
                 const W w = f.mul(y, T);
                 c.x[e] = f.add(x, w);
@@ -1016,7 +1050,8 @@ NTT_HD void prio_down() {
 // ---- the schedule (src/aie2.py:166-315, collapsed) ----------------------------
 // Exec supplies: each(fn) -- run fn(ctx) for this lane (GPU) or for all 256
 // contexts (host model); sync() -- workgroup barrier; lds() -- the tile.
-template <class Cfg, class Exec, int M32_MODE = -1>
+// SC: scaled inverse with N^-1 folded into stage 0 (fold_scale<Cfg>(); a.tw_sc set, a.do_scale set): no phase_scale
+template <class Cfg, class Exec, int M32_MODE = -1, bool SC = false>
 NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     using C = Ctx<Cfg>;
     constexpr int R = Cfg::R;
@@ -1116,7 +1151,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         static_for<0, R>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             constexpr int r = Cfg::INV ? R - 1 - k : k;
-            ex.each([&](C &c) { phase_compute<Cfg, r, M32_MODE>(c, a); });
+            ex.each([&](C &c) { phase_compute<Cfg, r, M32_MODE, false, SC>(c, a); });
             if constexpr (k < R - 1) {
                 constexpr int rn = Cfg::INV ? r - 1 : r + 1;
                 if constexpr (LATE_SYNC && k == 0) {
@@ -1129,7 +1164,9 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
                 prio_down<4>();
             }
         });
-        if constexpr (Cfg::INV) ex.each([&](C &c) { phase_scale<Cfg>(c, a); });
+        // (a configuration that CAN fold the scaling never runs the sweep: its launcher picks SC whenever do_scale is set, so
+        // the unscaled kernel carries neither the sweep's code nor its 24 scratch registers)
+        if constexpr (Cfg::INV && !SC && !fold_scale<Cfg>()) ex.each([&](C &c) { phase_scale<Cfg>(c, a); });
         ex.each([&](C &c) { phase_canon<Cfg>(c, a); });
         if constexpr (Cfg::DIRECT_STORE) {
             prio_up<2>();
@@ -1324,7 +1361,7 @@ struct ProductCfg {
     using CF = PassCfg<FieldGL, LOG_M, 0, true, false, NTT_PRODUCT_MASK(R, UNIFORM_TOP), 3, LOG_NT, false>;
 };
 
-// 4-byte words: radix-16 rounds in 256-thread workgroups (the shape of every 4-byte CONTIG pass), unit sizes 2^5 .. 2^12
+// 4-byte words: radix-16 rounds in 256-thread workgroups (the shape of every 4-byte CONTIG pass; 512 threads for the 13-stage unit), unit sizes 2^5 .. 2^13
 // (two rounds at least); only the innermost round's twiddles stay in registers, the others come from the LDS table.
 template <int LOG_M>
 struct ProductCfgM32 {

@@ -14,6 +14,7 @@ constexpr uint64_t GOLDILOCKS = 0xFFFFFFFF00000001ULL;
 constexpr int MAX_CONTIG_LOG_M = 12;  // 4096 words per workgroup tile
 constexpr int MIN_COL_LOG_M = 4;
 constexpr int MAX_COL_LOG_M = 8;
+constexpr int MAX_COL_LOG_M_WIDE = 9;  // 512 rows x one 128-byte segment (one more thread bit): used for N = 2^22 = 13 + 9
 
 struct PassDesc {
     bool contig;
@@ -76,9 +77,11 @@ inline std::vector<PassDesc> plan_passes(int n, int word_bytes = 8) {
     // ... and both word sizes reach N = 2^21 in two passes, 13 + 8 (8-byte words: 4.40 instead of 4.80 ms per 4 GiB in three; their
     // 13-stage pass re-reads its twiddles from L2 every round (128 VGPRs, two 512-thread workgroups per CU), which at N = 2^13 alone
     // is worth -11 % at saturating batches but +22 % for a single polynomial, so 8-byte N = 2^13 stays 7 + 6)
-    if (n == MAX_CONTIG_LOG_M_W4 + MAX_COL_LOG_M) {
+    // ... and N = 2^22 = 13 + 9: the 9-stage column pass (512 rows per tile, 512 / 1024 threads) saves the third HBM trip
+    // (round 3; 8 + 7 + 7 before)
+    if (n == MAX_CONTIG_LOG_M_W4 + MAX_COL_LOG_M || n == MAX_CONTIG_LOG_M_W4 + MAX_COL_LOG_M_WIDE) {
         v.push_back({true, 0, MAX_CONTIG_LOG_M_W4});
-        v.push_back({false, MAX_CONTIG_LOG_M_W4, MAX_COL_LOG_M});
+        v.push_back({false, MAX_CONTIG_LOG_M_W4, n - MAX_CONTIG_LOG_M_W4});
         return v;
     }
     if (n <= MAX_CONTIG_LOG_M + MAX_COL_LOG_M) {
@@ -107,6 +110,52 @@ inline std::vector<PassDesc> plan_passes(int n, int word_bytes = 8) {
         rest -= m;
     }
     return v;
+}
+
+// ---- plan alternatives: the decomposition is chosen at LAUNCH, by batch size, among candidates fixed at plan creation by
+// (N, word size, modulus class).  The twiddle tables are direction- and split-agnostic (a pass addresses T by stage and
+// block), so an alternative costs no device memory.  What the reference does with its one knob: the slab size follows
+// from N and the core count (src/aie2.py:21-28).
+//
+// Rule: alternatives are ordered by ascending `min_batch`; the launcher takes the LAST one whose min_batch <= batch
+// (alternative 0 has min_batch 0).  Thresholds are measured crossovers (profiles/r03_plan_alternatives.txt):
+//   * a long single pass (13 / 14 stages in 512 / 1024-thread workgroups, two / one per CU) beats two short passes once the
+//     batch fills the device, and loses for a handful of polynomials (round 2: 8-byte N = 2^13 in one pass -11 % at
+//     saturating batches, +22 % for one polynomial; 4-byte N = 2^14 with a lazy prime -21 % / +20 %).
+struct PlanAlt {
+    std::vector<PassDesc> passes;
+    uint64_t min_batch;
+};
+
+// modulus classes of the 4-byte-word kernels (pass_kernel.inc picks the instruction stream the same way)
+inline bool m32_lazy_modulus(uint64_t p) { return p < 0x40000000ull; }
+
+#ifndef NTT_ALT_MIN_BATCH_GL13
+#define NTT_ALT_MIN_BATCH_GL13 1024   // 8-byte N = 2^13: one 13-stage pass from this batch on (two workgroups per CU: 512 in flight)
+#endif
+#ifndef NTT_ALT_MIN_BATCH_M32_14
+#define NTT_ALT_MIN_BATCH_M32_14 512  // 4-byte lazy primes, N = 2^14: one 14-stage pass (one 1024-thread workgroup per CU)
+#endif
+
+inline std::vector<PlanAlt> plan_alternatives(int n, int word_bytes, uint64_t p) {
+    std::vector<PlanAlt> alts;
+    std::vector<PassDesc> def = plan_passes(n, word_bytes);
+    if (word_bytes == 4 && !m32_lazy_modulus(p) && n == 16) {
+        // carry-select / v_min streams (p >= 2^30): 8 + 8 beats 10 + 6 by 1.5 % (profiles/r02_split_sweep_final.txt); the
+        // lazy stream's lighter butterflies move the optimum to 10 + 6 (-7.2 %), which is plan_passes()'s table
+        def = {{true, 0, 8}, {false, 8, 8}};
+    }
+    alts.push_back({def, 0});
+    if (word_bytes == 8 && n == 13) alts.push_back({{{true, 0, 13}}, NTT_ALT_MIN_BATCH_GL13});
+    if (word_bytes == 4 && m32_lazy_modulus(p) && n == 14) alts.push_back({{{true, 0, 14}}, NTT_ALT_MIN_BATCH_M32_14});
+    return alts;
+}
+
+inline int select_alternative(const std::vector<PlanAlt> &alts, uint64_t batch) {
+    int k = 0;
+    for (size_t i = 1; i < alts.size(); i++)
+        if (batch >= alts[i].min_batch) k = (int) i;
+    return k;
 }
 
 // Montgomery constants of FieldM32

@@ -105,6 +105,29 @@ class NTTPlan:
         return [("contig" if i == 0 else "col", int(L.ntt_plan_info(self._h, 64 + i)), int(L.ntt_plan_info(self._h, 32 + i)))
                 for i in range(self.hbm_passes)]
 
+    def passes_for(self, batch: int) -> list[tuple[str, int, int]]:
+        """The decomposition ntt_forward / ntt_inverse run for THIS batch (the plan keeps alternatives and the launcher picks
+        by batch size and modulus class; `passes` is the default one)."""
+        L = _lib.lib()
+        alt = int(L.ntt_plan_select(self._h, batch))
+        k = int(L.ntt_plan_info(self._h, 256 + 16 * alt))
+        return [("contig" if i == 0 else "col", int(L.ntt_plan_info(self._h, 256 + 16 * alt + 8 + i)),
+                 int(L.ntt_plan_info(self._h, 256 + 16 * alt + 1 + i))) for i in range(k)]
+
+    def set_policy(self, alternative: int) -> None:
+        """-1 (default): the launcher picks the decomposition by batch; k >= 0: always alternative k (ntt_plan_set_policy)."""
+        check(_lib.lib().ntt_plan_set_policy(self._h, alternative), "ntt_plan_set_policy")
+
+    def clone(self, device: int | None = None) -> "NTTPlan":
+        """A copy of this plan on `device` (default: the same one): tables travel device-to-device (ntt_plan_clone)."""
+        device = self.device if device is None else device
+        new = object.__new__(NTTPlan)
+        new.logn, new.n, new.p, new.word_bytes, new.device = self.logn, self.n, self.p, self.word_bytes, device
+        new._h = C.c_void_p()
+        new.table = self.table
+        check(_lib.lib().ntt_plan_clone(self._h, device, C.byref(new._h)), "ntt_plan_clone")
+        return new
+
     @property
     def has_inverse(self) -> bool:
         return bool(_lib.lib().ntt_plan_info(self._h, 4))

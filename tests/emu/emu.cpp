@@ -139,6 +139,7 @@ struct Erased {
     const void *in;
     void *out;
     const void *tw;
+    const void *tw_sc;  // Goldilocks scaled inverse: stage-0 twiddles * N^-1 (N/2 words), as ntt_api.hip prepares them
     uint32_t p, pinv, r2;
     int n, s0;
     uint32_t batch;
@@ -222,6 +223,13 @@ int run_cfg(const Erased &e) {
     a.in = (const W *) e.in;
     a.out = (W *) e.out;
     a.tw = (const W *) e.tw;
+    a.tw_sc = nullptr;
+    constexpr bool CAN_FOLD = fold_scale<Cfg>();
+    const bool sc = CAN_FOLD && e.do_scale;  // the launcher's rule (pass_kernel.inc: launch_cfg)
+    if (sc) {
+        if (!e.tw_sc) return -2;
+        a.tw_sc = (const W *) e.tw_sc;
+    }
     a.field = make_field<typename Cfg::F>(e);
     a.n = e.n;
     a.s0 = e.s0;
@@ -250,14 +258,20 @@ int run_cfg(const Erased &e) {
             ex.tr.reset(ex.tile.data(), ex.tile.size(), sizeof(W));
             ex.tr.what = Cfg::CONTIG ? "CONTIG pass" : "column pass";
             ntt::lds_track() = &ex.tr;
+            auto go = [&]() {
+                if constexpr (CAN_FOLD) {
+                    if (sc) return run_pass<Cfg, EmuExec<Cfg>, -1, true>(ex, a);
+                }
+                return run_pass<Cfg>(ex, a);
+            };
             if constexpr (Cfg::WAVE_LOCAL) {
                 for (int w = 0; w < Cfg::NT / 64; w++) {
                     ex.only_wave = w;
-                    run_pass<Cfg>(ex, a);
+                    go();
                     memset(ex.tile.data(), 0x5A, ex.tile.size() * sizeof(W));  // nothing may survive
                 }
             } else {
-                run_pass<Cfg>(ex, a);
+                go();
             }
             ntt::lds_track() = nullptr;
         }
@@ -274,6 +288,10 @@ int dispatch(bool contig, int log_m, const Erased &e) {
         return run_cfg<ColPassCfg<F, M, INV>>(e);
     if (contig) {
         if (log_m == 13) return run_cfg<PassCfg<F, 13, 0, true, INV, sizeof(typename F::W) == 4 ? 0xF : 0x8, 4, 9>>(e);  // pass_kernel.inc: ContigCfg13
+        if (log_m == 14) {  // pass_kernel.inc: ContigCfg14 (4-byte words only)
+            if constexpr (sizeof(typename F::W) == 4) return run_cfg<PassCfg<F, 14, 0, true, INV, 0xF, 4, 10>>(e);
+            else return -1;
+        }
         if (contig_log_e(log_m, sizeof(typename F::W), e.s0 + log_m == e.n) == 3) {
             if constexpr (!INV) {
                 if (e.in2 != nullptr) {  // fused product: the non-DMA twins (pass_kernel.inc)
@@ -299,7 +317,7 @@ int dispatch(bool contig, int log_m, const Erased &e) {
         }
     }
     switch (log_m) {
-        CASE_COL(4) CASE_COL(5) CASE_COL(6) CASE_COL(7) CASE_COL(8)
+        CASE_COL(4) CASE_COL(5) CASE_COL(6) CASE_COL(7) CASE_COL(8) CASE_COL(9)
         default: return -1;
     }
 }
@@ -333,6 +351,12 @@ int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, con
         for (size_t i = 0; i < N; i++) t64[i] = to_table_form(src[i], p, 8);
         tw = t64.data();
     }
+    std::vector<uint64_t> tsc;  // stage-0 twiddles of the scaled Goldilocks inverse, as ntt_plan_set_twiddles makes them
+    if (inverse && word_bytes == 8) {
+        const uint64_t ninv = powmod((p + 1) / 2, (uint64_t) logn, p);
+        tsc.resize(N / 2);
+        for (size_t i = 0; i < N / 2; i++) tsc[i] = to_table_form(mulmod(Ti[N / 2 + i], ninv, p), p, 8);
+    }
     std::vector<PassDesc> passes;
     if (passes_override == 0) {
         passes = plan_passes(logn, word_bytes);
@@ -359,6 +383,7 @@ int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, con
     e.layout = layout;
     e.target_wgs = target_wgs;
     e.tw = tw;
+    e.tw_sc = tsc.empty() ? nullptr : tsc.data();
     e.scale = to_table_form(powmod((p + 1) / 2, (uint64_t) logn, p), p, word_bytes);
     const void *cur = in;
     const size_t np = passes.size();
@@ -491,6 +516,24 @@ int emu_polymul_fused(int word_bytes, int logn, uint64_t p, const void *T_plain,
         if (rc) return rc;
     }
     return 0;
+}
+
+// alternative `alt` of plan_alternatives(logn, word_bytes, p): writes up to 8 (contig, s0, log_m) triples, *min_batch;
+// returns the number of passes, or -1 when there is no such alternative
+int emu_plan_alt(int logn, int word_bytes, uint64_t p, int alt, int *out_triples, uint64_t *min_batch) {
+    auto alts = plan_alternatives(logn, word_bytes, p);
+    if (alt < 0 || alt >= (int) alts.size()) return -1;
+    const auto &v = alts[(size_t) alt].passes;
+    *min_batch = alts[(size_t) alt].min_batch;
+    for (size_t i = 0; i < v.size() && i < 8; i++) {
+        out_triples[3 * i] = v[i].contig;
+        out_triples[3 * i + 1] = v[i].s0;
+        out_triples[3 * i + 2] = v[i].log_m;
+    }
+    return (int) v.size();
+}
+int emu_select_alt(int logn, int word_bytes, uint64_t p, uint64_t batch) {
+    return select_alternative(plan_alternatives(logn, word_bytes, p), batch);
 }
 
 // the planner's split, for tests: writes up to 8 (contig, s0, log_m) triples

@@ -94,3 +94,38 @@ def test_product_library_reads_no_environment_and_has_no_experiment_paths(hiplib
     for name in (b"NTT_DEBUG_FLAGS", b"NTT_FUSED", b"NTT_PLAN_SPLIT", b"NTT_TARGET_WGS", b"NTT_ONLY_PASS", b"fused_gl16"):
         assert name not in blob, name
     assert not os.path.exists(os.path.join(ROOT, "ntt_aie_amd", "csrc", "fused_gl16.hip"))
+
+
+def test_package_reads_no_ntt_environment_variable(hiplib, tmp_path):
+    """include/ntt_hip.h promises that no environment variable can change a result.  True of the library (test above) and of
+    the Python package: no source under ntt_aie_amd/*.py touches os.environ / getenv, the only NTT_* name in the C sources of
+    the product build is NTT_ROCTX (profiling ranges on/off), and the package refuses an experiment build unless a tool asks
+    for it in code (use_library(..., allow_experiment=True))."""
+    pkg = os.path.join(ROOT, "ntt_aie_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            text = open(os.path.join(pkg, f)).read()
+            assert "os.environ" not in text and "getenv" not in text, f
+    api = open(os.path.join(pkg, "csrc", "ntt_api.hip")).read()
+    product_side = re.sub(r"#if defined\(NTT_EXPERIMENT\).*?#endif", "", api, flags=re.S)
+    assert set(re.findall(r'getenv\("([A-Z_0-9]+)"\)', product_side)) == {"NTT_ROCTX"}
+    for f in os.listdir(os.path.join(pkg, "csrc")):
+        if f.endswith((".h", ".inc", ".hip")) and f != "ntt_api.hip":
+            assert "getenv" not in open(os.path.join(pkg, "csrc", f)).read(), f
+    # the product library is not an experiment build; the experiment build (when present) is refused by default
+    assert not hiplib.is_experiment_build(hiplib.lib())
+    exp = os.path.join(pkg, "libntt_hip_exp.so")
+    if os.path.exists(exp):
+        import subprocess
+        import sys
+
+        code = ("import sys; sys.path.insert(0, %r)\nfrom ntt_aie_amd import _lib\n_lib.use_library(%r)\n"
+                "try:\n    _lib.lib()\nexcept ImportError as e:\n    print('REFUSED'); sys.exit(0)\nprint('LOADED')" % (ROOT, exp))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, NTT_HIP_LIB=exp))
+        assert "REFUSED" in out.stdout, out.stdout + out.stderr
+        # ... and a stray NTT_HIP_LIB in the environment is ignored by the package
+        code = ("import sys; sys.path.insert(0, %r)\nfrom ntt_aie_amd import _lib\nprint(_lib.LIB_PATH)" % ROOT)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                             env=dict(os.environ, NTT_HIP_LIB=exp))
+        assert out.stdout.strip().endswith("libntt_hip.so"), out.stdout + out.stderr

@@ -49,17 +49,21 @@ def test_single_pass_sizes(oracle, wb, p, g):
 
 @pytest.mark.parametrize("wb,p,g", FIELDS[:2])
 def test_multi_pass_planner_splits(oracle, wb, p, g):
-    for logn in (13, 14, 16, 17, 21):  # 2^21 = 13 + 8
+    for logn in (13, 14, 16, 17, 21, 22):  # 2^21 = 13 + 8, 2^22 = 13 + 9 (the 512-row column tile)
         for inv in (0, 1):
             _run(oracle, wb, logn, p, g, 3 if logn < 21 else 1, inverse=inv, layout=1, tw=8, seed=logn, inplace=True)
 
 
 @pytest.mark.parametrize("ov", [(8, 4), (8, 5), (7, 6), (8, 7), (8, 8), (9, 4), (10, 4), (11, 5), (12, 4), (5, 4), (4, 6), (5, 6), (6, 7),
-                                (5, 5, 8), (13,), (13, 4), (7, 8), (9, 6), (10, 6)])
+                                (5, 5, 8), (13,), (13, 4), (7, 8), (9, 6), (10, 6), (8, 9), (5, 9), (14,), (14, 5)])
 def test_every_tile_shape(oracle, ov):
     logn = sum(ov)
-    for wb, p, g in FIELDS[:2]:
+    for wb, p, g in FIELDS[:2] + [(4, 998244353, 3)]:
         if wb == 4 and ov[0] < 5:  # column tiles of 4-byte words are 32 words wide: first pass >= 5 stages
+            continue
+        if wb == 8 and ov[0] == 14:  # the 14-stage tile exists for 4-byte words only
+            continue
+        if p == 998244353 and ov[0] != 14:  # the lazy modulus class: the shape the planner actually picks the 14-stage pass for
             continue
         for inv in (0, 1):
             _run(oracle, wb, logn, p, g, 2, inverse=inv, scale=inv, tw=4, ov=emu_lib.pack_passes(*ov), seed=7)
@@ -77,10 +81,44 @@ def test_planner_covers_all_sizes():
             if k > 1:
                 assert s0 >= (4 if wb == 8 else 5)  # column tiles are 16 / 32 words wide
             for contig, s, m in passes[1:]:
-                assert contig == 0 and s == s0 and 4 <= m <= 8
+                assert contig == 0 and s == s0 and 4 <= m <= (9 if logn == 22 else 8)
                 s0 += m
             assert s0 == logn
-            assert k == (1 if logn <= top else max(2, 1 + -(-(logn - 13) // 8)))  # fewest HBM passes (the 13-stage pass: 2^21 in two)
+            # fewest HBM passes (the 13-stage pass: 2^21 in two; with the 9-stage column pass 2^22 too)
+            assert k == (1 if logn <= top else 2 if logn == 22 else max(2, 1 + -(-(logn - 13) // 8)))
+
+
+def test_plan_alternatives():
+    """plan.h: plan_alternatives / select_alternative -- the decomposition is picked at launch by batch among candidates fixed
+    by (N, word size, modulus class).  Alternative 0 always exists with min_batch 0; thresholds ascend; every alternative
+    covers all stages; the documented cases are present."""
+    L = emu_lib.lib()
+    L.emu_plan_alt.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+    L.emu_select_alt.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64]
+    tri, mb = (C.c_int * 24)(), C.c_uint64(0)
+
+    def alts(logn, wb, p):
+        out = []
+        for a in range(8):
+            k = L.emu_plan_alt(logn, wb, p, a, tri, C.byref(mb))
+            if k < 0:
+                break
+            out.append(([tri[3 * i + 2] for i in range(k)], int(mb.value)))
+            assert sum(out[-1][0]) == logn and [tri[3 * i + 1] for i in range(k)] == [sum(out[-1][0][:i]) for i in range(k)]
+        return out
+
+    for wb, p in ((8, GOLD), (4, 3221225473), (4, 998244353), (4, 3329), (4, 2013265921)):
+        for logn in range(1, 29):
+            a = alts(logn, wb, p)
+            assert a and a[0][1] == 0 and [x[1] for x in a] == sorted(x[1] for x in a)
+            for batch in (1, 2, 100, 511, 512, 1023, 1024, 4096, 1 << 20):
+                k = L.emu_select_alt(logn, wb, p, batch)
+                assert 0 <= k < len(a) and batch >= a[k][1] and all(batch < x[1] for x in a[k + 1:])
+    g13 = alts(13, 8, GOLD)
+    assert g13[0][0] == [7, 6] and g13[1][0] == [13] and g13[1][1] >= 64      # one long pass only once the batch fills the device
+    assert alts(14, 4, 998244353)[1][0] == [14] and len(alts(14, 4, 3221225473)) == 1  # the 14-stage pass pays for lazy primes only
+    assert alts(16, 4, 998244353)[0][0] == [10, 6] and alts(16, 4, 3221225473)[0][0] == [8, 8]  # split by modulus class
+    assert alts(22, 8, GOLD)[0][0] == [13, 9] and alts(22, 4, 3329)[0][0] == [13, 9]
 
 
 def test_field_arithmetic_edges():

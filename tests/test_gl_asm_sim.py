@@ -53,7 +53,7 @@ def _cases(rng, pool_x, pool_y, n_random):
 def test_goldilocks_streams(gen, vbase):
     rng = random.Random(vbase)
     tw = EDGE + [rng.randrange(P) for _ in range(6)]
-    for kind in ("fwd", "inv", "mul"):
+    for kind in ("fwd", "inv", "mul") + (("invs",) if vbase != 56 else ()):
         lines = gen.stream(kind, 2, vbase)
         canon_in = kind == "fwd"  # forward butterflies take canonical words; the others any 64-bit representative of x
         pool_x = EDGE if canon_in else ANY
@@ -67,9 +67,16 @@ def test_goldilocks_streams(gen, vbase):
                 vals = [{"x": x, "y": y, "t": t}, {"x": y if canon_in else x ^ 1, "y": x % P, "t": tw[(n + 3) % len(tw)]}]
                 if kind == "mul":
                     vals = [{"x": v["x"], "t": v["t"]} for v in vals]
-                env = gen.simulate(lines, _env64(vbase, vals))
+                e0 = _env64(vbase, vals)
+                cs = tw[(n + 5) % len(tw)]  # the folded scale constant of the "invs" stream (any canonical word)
+                e0["%[c0]"], e0["%[c1]"] = cs & 0xFFFFFFFF, cs >> 32
+                env = gen.simulate(lines, e0)
                 for b, v in enumerate(vals):
                     gx = _get(env, "x", b)
+                    if kind == "invs":  # u = x*c, w = y*(T*c): both outputs canonical, x any 64-bit representative
+                        u, w = v["x"] * cs * RINV % P, v["y"] * v["t"] * RINV % P
+                        assert gx == (u + w) % P and _get(env, "y", b) == (u - w) % P, (kind, v, cs)
+                        continue
                     if kind == "fwd":
                         assert gx == (v["x"] + v["y"]) % P, (kind, v)
                         assert _get(env, "y", b) == (v["x"] - v["y"]) * v["t"] * RINV % P, (kind, v)

@@ -1,0 +1,120 @@
+"""The counter summaries that bench.py quotes (tools/pmc_summary.py, tools/sq_summary.py) key a kernel by its FULL
+PassCfg<...> argument list: a CSV holding the forward AND the inverse kernel of one pass shape yields two entries, and
+bench.py's forward_counters() can only ever return the forward one.  CPU only: synthetic CSVs."""
+import csv
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+HDR = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id", "Grid_Size", "Kernel_Id", "Kernel_Name",
+       "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Counter_Name",
+       "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+
+
+def kname(log_m, log_c, contig, inv, log_e):
+    cfg = "ntt::PassCfg<ntt::FieldGL, %d, %d, %s, %s, 15, %d, 8, true>" % (log_m, log_c, str(contig).lower(), str(inv).lower(), log_e)
+    return "void ntt::(anonymous namespace)::pass_kernel<%s >(ntt::PassArgs<%s >)" % (cfg, cfg)
+
+
+KERNELS = {  # (contig, inv) -> name
+    (True, False): kname(8, 0, True, False, 3), (True, True): kname(8, 0, True, True, 3),
+    (False, False): kname(8, 4, False, False, 4), (False, True): kname(8, 4, False, True, 4),
+}
+OTHER = "void at::native::vectorized_elementwise_kernel<4, at::native::BinaryFunctor<long> >(int)"
+
+
+def write_csv(path, rows):
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
+        w.writerow(HDR)
+        for i, (name, grid, counter, value, t0, t1) in enumerate(rows):
+            w.writerow([i, i, "Agent 2", 1, 1, 1, grid, 7, name, 256, 32768, 0, 96, 0, 96, counter, value, t0, t1])
+
+
+def test_parse_pass_kernel_full_argument_list():
+    from kernel_key import parse_pass_kernel
+
+    f, i = parse_pass_kernel(KERNELS[(True, False)]), parse_pass_kernel(KERNELS[(True, True)])
+    assert f["key"] != i["key"] and not f["inv"] and i["inv"]
+    assert f["short"] == "pass_contig_8_fwd" and i["short"] == "pass_contig_8_inv"
+    assert f["key"] == "PassCfg<ntt::FieldGL, 8, 0, true, false, 15, 3, 8, true>"
+    c = parse_pass_kernel(KERNELS[(False, True)])
+    assert c["short"] == "pass_col_8_inv" and c["log_c"] == 4 and c["log_e"] == 4 and c["field"] == "FieldGL"
+    assert parse_pass_kernel(OTHER) is None
+
+
+def test_sq_summary_keeps_directions_apart(tmp_path):
+    import sq_summary
+
+    wave_bf = 4096 * 32768 * 8 / 64
+    rows = []
+    # forward kernels: 22.9 / 22.3 instructions per butterfly; inverse: 25 / 21 -- round 2's summary averaged them
+    for (contig, inv), ipb, cyc in (((True, False), 22.9, 1.6e6), ((True, True), 25.0, 1.8e6), ((False, False), 22.3, 1.55e6),
+                                    ((False, True), 21.0, 1.5e6)):
+        for rep in range(3):
+            t0 = 1000000 * (rep + 1)
+            rows.append((KERNELS[(contig, inv)], 2097152, "SQ_INSTS_VALU", ipb * wave_bf, t0, t0 + 800000))
+            rows.append((KERNELS[(contig, inv)], 2097152, "SQ_ACTIVE_INST_VALU", ipb * wave_bf, t0, t0 + 800000))
+            rows.append((KERNELS[(contig, inv)], 2097152, "GRBM_GUI_ACTIVE", 8 * cyc, t0, t0 + 800000))
+            rows.append((KERNELS[(contig, inv)], 2097152, "SQ_WAVE_CYCLES", 1.0e9, t0, t0 + 800000))
+        rows.append((KERNELS[(contig, inv)], 4096, "SQ_INSTS_VALU", 1.0, 1, 2))  # a tiny warm-up launch: filtered by grid size
+    rows.append((OTHER, 4194304, "SQ_INSTS_VALU", 1e9, 1, 2))
+    p = tmp_path / "sq.csv"
+    write_csv(p, rows)
+    d = sq_summary.summarize(str(p), batch=4096, logn=16, src_hash="abc")
+    assert len(d["kernels"]) == 4  # two shapes x two directions = four keys
+    by_short = {v["short"]: v for v in d["kernels"].values()}
+    assert set(by_short) == {"pass_contig_8_fwd", "pass_contig_8_inv", "pass_col_8_fwd", "pass_col_8_inv"}
+    assert by_short["pass_contig_8_fwd"]["valu_instr_per_butterfly"] == pytest.approx(22.9)
+    assert by_short["pass_contig_8_inv"]["valu_instr_per_butterfly"] == pytest.approx(25.0)
+    assert by_short["pass_col_8_fwd"]["valu_instr_per_butterfly"] == pytest.approx(22.3)
+    assert by_short["pass_contig_8_fwd"]["launches"] == 3
+    assert by_short["pass_contig_8_fwd"]["held_clock_GHz"] == pytest.approx(1.6e6 / 800000.0)  # cycles per ns
+    assert by_short["pass_contig_8_fwd"]["direction"] == "fwd" and by_short["pass_col_8_inv"]["direction"] == "inv"
+
+    # bench.py picks entries through kernel_key.forward_entry: never an inverse kernel
+    import bench
+
+    passes = [("contig", 0, 8), ("col", 8, 8)]
+    ent, why = bench.forward_counters(d, passes)
+    assert why is None and [e[1]["direction"] for e in ent] == ["fwd", "fwd"]
+    assert [e[1]["valu_instr_per_butterfly"] for e in ent] == [pytest.approx(22.9), pytest.approx(22.3)]
+    v = bench.valu_roofline(ent, passes, [0.83, 0.82], 4096, 16)
+    assert v["instr_per_butterfly"] == [pytest.approx(22.9), pytest.approx(22.3)]
+    assert v["peak_butterflies_per_s"] == pytest.approx(1024 * 2.4e9 / (4 * 22.6) * 64)
+    assert 0 < v["frac_at_2.4GHz"] < 1 and 0 < v["frac_at_held_clock"] <= 1
+    # a summary holding ONLY inverse kernels (what round 2's traffic file was) yields nothing
+    only_inv = {"kernels": {k: e for k, e in d["kernels"].items() if e["direction"] == "inv"}}
+    ent, why = bench.forward_counters(only_inv, passes)
+    assert ent is None and "no forward" in why
+
+
+def test_pmc_summary_keeps_directions_apart(tmp_path):
+    import pmc_summary
+
+    kib = 4 * 1024 * 1024  # 4 GiB in KiB
+    fr, wr = [], []
+    for (contig, inv), extra in (((True, False), 0), ((True, True), 1000), ((False, False), 0), ((False, True), 2000)):
+        for rep in range(2):
+            fr.append((KERNELS[(contig, inv)], 2097152, "FETCH_SIZE", kib / 4 + extra, 1, 2))  # the counter sees half of 2 GiB read
+            wr.append((KERNELS[(contig, inv)], 2097152, "WRITE_SIZE", kib / 2 + extra, 1, 2))
+        fr.append((KERNELS[(contig, inv)], 4096, "FETCH_SIZE", 16.0, 1, 2))  # parity-sized launch: dropped (< half of the largest)
+        wr.append((KERNELS[(contig, inv)], 4096, "WRITE_SIZE", 16.0, 1, 2))
+    pf, pw = tmp_path / "f.csv", tmp_path / "w.csv"
+    write_csv(pf, fr)
+    write_csv(pw, wr)
+    d = pmc_summary.summarize(str(pf), str(pw), src_hash="abc")
+    assert len(d["kernels"]) == 4
+    fwd = [v for v in d["kernels"].values() if v["direction"] == "fwd"]
+    assert len(fwd) == 2 and all(v["hbm_bytes_per_launch"] == pytest.approx(2 ** 32) for v in fwd)
+    inv = [v for v in d["kernels"].values() if v["direction"] == "inv"]
+    assert all(v["hbm_bytes_per_launch"] > 2 ** 32 for v in inv) and all(v["launches"] == 2 for v in inv)
+    import bench
+
+    ent, why = bench.forward_counters(d, [("contig", 0, 8), ("col", 8, 8)])
+    assert why is None and sum(e[1]["hbm_bytes_per_launch"] for e in ent) == pytest.approx(2 ** 33)

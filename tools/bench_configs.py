@@ -4,6 +4,9 @@ that one reports the headline config only).  Prints one JSON object per config."
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _explib
+_explib.select(default=None)  # the product library unless NTT_HIP_LIB names another build
 import numpy as np, torch
 from ntt_aie_amd import NTTPlan
 

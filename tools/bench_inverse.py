@@ -3,6 +3,9 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _explib
+_explib.select(default=None)  # the product library unless NTT_HIP_LIB names another build
 import torch
 from bench import GOLDILOCKS, synth_batch
 from ntt_aie_amd import NTTPlan

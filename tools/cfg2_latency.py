@@ -5,7 +5,9 @@ load, compute and store phases of all 1024 workgroups in lockstep.  Sweep of the
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("NTT_HIP_LIB", os.path.join(ROOT, "ntt_aie_amd", "libntt_hip_exp.so"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _explib
+_explib.select()  # the experiment build unless NTT_HIP_LIB names another one
 import torch
 from ntt_aie_amd import NTTPlan
 

@@ -5,7 +5,9 @@ import os, sys, time, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 # experiment knobs live only in libntt_hip_exp.so (make -C ntt_aie_amd/csrc exp): the product library reads no env
-os.environ.setdefault("NTT_HIP_LIB", os.path.join(ROOT, "ntt_aie_amd", "libntt_hip_exp.so"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _explib
+_explib.select()  # the experiment build unless NTT_HIP_LIB names another one
 os.environ["NTT_FUSED"] = "1"
 import torch
 from ntt_aie_amd import NTTPlan, to_device, to_host

@@ -4,6 +4,9 @@ with wb=4).  usage: fwd_inv_sweep.py wb logn [logn ...]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _explib
+_explib.select(default=None)  # the product library unless NTT_HIP_LIB names another build
 import torch
 from ntt_aie_amd import NTTPlan
 

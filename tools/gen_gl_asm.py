@@ -87,7 +87,7 @@ def butterfly(kind, b, vbase=104):
         ins.append(Ins(f"s_andn2_b64 {se}, {se}, {sf}", [se, sf], [se], salu=True))
         ins.append(Ins(f"v_addc_co_u32 {a1}, {sf}, {a1}, 0, {se}", [a1, se], [a1, sf]))
 
-    def mul(m0, m1, r0, r1):
+    def mul(m0, m1, r0, r1, t0=t0, t1=t1):
         # (m1:m0) * (t1:t0) * 2^-64 mod p, canonical; m may be any 64-bit value.
         # Product P = (P3:P2:P1:P0) by four v_mad_u64_u32 (the carry-outs that mean nothing go to sbb), H = (P3:P2).
         ins.append(Ins(f"v_mad_u64_u32 {P(L)}, {sbb}, {m0}, {t0}, 0", [m0, t0], [L[0], L[1], sbb]))
@@ -122,6 +122,13 @@ def butterfly(kind, b, vbase=104):
         lazy_add(x0, x1, d0, d1)
     elif kind == "mul":  # x' = x * T
         mul(x0, x1, x0, x1)
+    elif kind == "invs":  # LAST inverse stage with the N^-1 scaling folded in: w = y * (T*c) ; u = x * c ; x' = u + w ; y' = u - w
+        # t = T^-1 * N^-1 (a plan-time table, per block), c = N^-1 (wave-uniform, SGPRs): N/2 extra products per transform
+        # instead of the N of a separate scaling sweep.  x may be any 64-bit representative; both outputs are canonical.
+        mul(y0, y1, d0, d1)
+        mul(x0, x1, x0, x1, "%[c0]", "%[c1]")
+        sub(y0, y1, x0, x1, d0, d1, y0, y1, y0, y1)   # u, w canonical -> canonical difference
+        add(x0, x1, d0, d1, x0, x1)
     return ins
 
 
@@ -403,8 +410,12 @@ def emit(kind, nb, tw_constraint, vbase=104, suffix=""):
             args += [f"uint64_t &x{b}", f"uint64_t t{b}"]
         else:
             args += [f"uint64_t &x{b}", f"uint64_t &y{b}", f"uint64_t t{b}"]
+    if kind == "invs":
+        args += ["uint64_t c"]
     src = [f"// {kind} x{nb}: {len(lines)} instructions, {nops} s_nop",
            f"__device__ __forceinline__ void {name}({', '.join(args)}) {{"]
+    if kind == "invs":
+        src.append("    const uint32_t c0 = (uint32_t) c, c1 = (uint32_t) (c >> 32);")
     for b in range(nb):
         src.append(f"    uint32_t x0_{b} = (uint32_t) x{b}, x1_{b} = (uint32_t) (x{b} >> 32);")
         if kind != "mul":
@@ -428,8 +439,10 @@ def emit(kind, nb, tw_constraint, vbase=104, suffix=""):
             outs += [f'[y0_{b}] "+v"(y0_{b})', f'[y1_{b}] "+v"(y1_{b})']
             outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("d0_", "d1_")]
         ins_ += [f'[t0_{b}] "{tw_constraint}"(t0_{b})', f'[t1_{b}] "{tw_constraint}"(t1_{b})']
-    if kind == "fwd":
+    if kind in ("fwd", "invs"):
         ins_ += ['[pp] "s"(0xFFFFFFFF00000001ull)']  # p, for the 64-bit compare of the modular add
+    if kind == "invs":
+        ins_ += ['[c0] "s"(c0)', '[c1] "s"(c1)']
     ins_ += [f'[zero_{b}] "v"(zero_{b})' for b in range(nb)]
     clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 12 * nb) if r not in zero_regs] + [f'"s{r}"' for r in range(80, 80 + 10 * nb)]
     src.append("        : " + ", ".join(outs))
@@ -459,6 +472,12 @@ def main():
             txt, n, nops = emit(kind, 2, "v", vbase=72, suffix="_lo")
             out.append(txt)
             out.append("")
+        if kind == "inv":  # the scaled last stage of the inverse transform (stage 0: its twiddles differ per thread -> "v" only)
+            for vb, sfx in ((104, ""), (72, "_lo")):
+                txt, n, nops = emit("invs", 2, "v", vbase=vb, suffix=sfx)
+                out.append(txt)
+                out.append("")
+            print(f"invs x2: {n} instructions, {nops} nops", file=sys.stderr)
         if kind != "mul":
             for tw in ("v", "s"):  # for the radix-8 (light) kernels: scratch lives lower
                 for vb, sfx in ((72, "_lo"), (56, "_lo2")):

@@ -7,7 +7,9 @@ usage: mall_probe.py [logn=16] [batch=4096]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("NTT_HIP_LIB", os.path.join(ROOT, "ntt_aie_amd", "libntt_hip_exp.so"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _explib
+_explib.select()  # the experiment build unless NTT_HIP_LIB names another one
 import torch
 from ntt_aie_amd import NTTPlan
 

@@ -1,28 +1,77 @@
 #!/usr/bin/env python3
 """Reduce a rocprofv3 --pmc SQ_* GRBM_GUI_ACTIVE counter_collection.csv of the bench command to per-kernel figures:
-VALU instructions per butterfly, mean waves per SIMD, VALU instruction count x 4 cycles over the kernel cycles, stall split.
-usage: sq_summary.py counter_collection.csv > profiles/rNN_sq_counters.json"""
+VALU instructions per butterfly, mean waves per SIMD, VALU instruction count x 4 cycles over the kernel cycles, stall split,
+launch duration and the shader clock the kernel held (GRBM_GUI_ACTIVE / 8 XCDs / duration).
+usage: sq_summary.py counter_collection.csv [--batch 4096] [--logn 16] > profiles/rNN_sq_counters.json
+
+Kernels are keyed by their FULL PassCfg<...> argument list (tools/kernel_key.py): the forward and the inverse kernel of one
+pass shape are two entries, never averaged together."""
 import collections, csv, json, os, sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ntt_aie_amd._lib import kernel_source_hash  # the kernels these counters belong to (bench.py checks it)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_key import parse_pass_kernel
 
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for r in csv.DictReader(open(sys.argv[1])):
-    if "pass_kernel" in r["Kernel_Name"] and int(r["Grid_Size"]) >= 1000000:
-        cfg = r["Kernel_Name"].split("PassCfg<")[1].split(">")[0].split(",")
-        acc["pass_%s_%s" % ("contig" if cfg[3].strip() == "true" else "col", cfg[1].strip())][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {"src_hash": kernel_source_hash(), "note": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU "
-               "SQ_INSTS_VALU GRBM_GUI_ACTIVE -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline (one pass, 8 SQ slots); SQ_* cycle "
-               "counters are quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs; means over the batch-4096 launches "
-               "(N = 2^16: 4096 * 32768 * 8 butterflies per launch, 1024 SIMDs); valu_instr_x4cyc_over_kernel_cycles = SQ_INSTS_VALU x an ASSUMED 4 cycles per wave-instruction / (1024 SIMDs x kernel cycles): an instruction-count estimate, not a busy-cycle measurement (SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU on this counter set)", "kernels": {}}
-for k, v in acc.items():
-    m = {c: sum(x) / len(x) for c, x in v.items()}
-    cyc = m["GRBM_GUI_ACTIVE"] / 8
-    m.update(kernel_cycles=cyc, mean_waves_per_simd=m["SQ_WAVE_CYCLES"] * 4 / cyc / 1024,
-             valu_instr_x4cyc_over_kernel_cycles=m["SQ_ACTIVE_INST_VALU"] * 4 / cyc / 1024,
-             wave_parked_frac=m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], wave_issue_stall_frac=m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"],
-             valu_instr_per_butterfly=m["SQ_INSTS_VALU"] / (4096 * 32768 * 8 / 64))
-    out["kernels"][k] = m
-json.dump(out, sys.stdout, indent=1)
-print()
+SIMDS = 1024  # 256 CUs x 4
+
+
+def summarize(path, batch=4096, logn=16, min_grid=1000000, src_hash=None):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for r in csv.DictReader(open(path, newline="")):
+        pk = parse_pass_kernel(r["Kernel_Name"])
+        if pk is None or int(r["Grid_Size"]) < min_grid:
+            continue
+        acc[pk["key"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+            acc[pk["key"]]["_dur_ns"].append(float(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        meta[pk["key"]] = pk
+    out = {"src_hash": src_hash,
+           "note": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU "
+                   "SQ_INSTS_VALU GRBM_GUI_ACTIVE -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-valu-floor (one pass, 8 SQ "
+                   "slots); SQ_* cycle counters are quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs; means over the "
+                   "batch-%d launches (N = 2^%d: batch * N/2 * LOG_M butterflies per launch, %d SIMDs); one entry per kernel instantiation, "
+                   "keyed by the full PassCfg<...> argument list (INV = 5th argument); valu_instr_x4cyc_over_kernel_cycles = SQ_INSTS_VALU x "
+                   "an ASSUMED 4 cycles per wave-instruction / (%d SIMDs x kernel cycles): an instruction-count estimate, not a busy-cycle "
+                   "measurement (SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU on this counter set); held_clock_GHz = GRBM_GUI_ACTIVE / 8 / "
+                   "launch duration under the profiler" % (batch, logn, SIMDS, SIMDS),
+           "batch": batch, "logn": logn, "kernels": {}}
+    for k, v in acc.items():
+        m = {c: sum(x) / len(x) for c, x in v.items() if not c.startswith("_")}
+        pk = meta[k]
+        wave_butterflies = batch * (1 << (logn - 1)) * pk["log_m"] / 64.0
+        m.update(short=pk["short"], direction="inv" if pk["inv"] else "fwd", launches=len(v["SQ_INSTS_VALU"]) if "SQ_INSTS_VALU" in v else 0)
+        if "GRBM_GUI_ACTIVE" in m:
+            cyc = m["GRBM_GUI_ACTIVE"] / 8
+            m["kernel_cycles"] = cyc
+            if v.get("_dur_ns"):
+                dur = sum(v["_dur_ns"]) / len(v["_dur_ns"])
+                m["duration_us"] = dur / 1e3
+                m["held_clock_GHz"] = cyc / dur
+            if "SQ_WAVE_CYCLES" in m:
+                m["mean_waves_per_simd"] = m["SQ_WAVE_CYCLES"] * 4 / cyc / SIMDS
+            if "SQ_INSTS_VALU" in m:
+                m["valu_instr_x4cyc_over_kernel_cycles"] = m["SQ_INSTS_VALU"] * 4 / cyc / SIMDS
+        if "SQ_WAVE_CYCLES" in m:
+            if "SQ_WAIT_ANY" in m:
+                m["wave_parked_frac"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
+            if "SQ_WAIT_INST_ANY" in m:
+                m["wave_issue_stall_frac"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
+        if "SQ_INSTS_VALU" in m:
+            m["valu_instr_per_butterfly"] = m["SQ_INSTS_VALU"] / wave_butterflies
+        out["kernels"][k] = m
+    return out
+
+
+def main():
+    from ntt_aie_amd._lib import kernel_source_hash  # the kernels these counters belong to (bench.py checks it)
+
+    a = sys.argv[1:]
+    batch = int(a[a.index("--batch") + 1]) if "--batch" in a else 4096
+    logn = int(a[a.index("--logn") + 1]) if "--logn" in a else 16
+    json.dump(summarize(a[0], batch, logn, src_hash=kernel_source_hash()), sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()

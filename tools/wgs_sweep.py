@@ -4,7 +4,9 @@ per-pass kernel time (hipEvents, median of 15).  usage: wgs_sweep.py wb logn bat
 import os, statistics, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("NTT_HIP_LIB", os.path.join(ROOT, "ntt_aie_amd", "libntt_hip_exp.so"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import _explib
+_explib.select()  # the experiment build unless NTT_HIP_LIB names another one
 import torch
 from ntt_aie_amd import NTTPlan
 
