@@ -130,21 +130,21 @@ struct PlanAlt {
 // modulus classes of the 4-byte-word kernels (pass_kernel.inc picks the instruction stream the same way)
 inline bool m32_lazy_modulus(uint64_t p) { return p < 0x40000000ull; }
 
+// measured crossovers (same process, tools/run_plan_alternatives_r03.sh -> profiles/r03_plan_alternatives.txt):
+//   8-byte N = 2^13, 7 + 6 -> 13:  batch 1 +23 %, 32 +15 %, 64 +7 %, 128 -7.5 %, 256 -13 %, 2048 -17 %, 65536 -10 % (inverse -6 .. -22 %)
+//   4-byte lazy N = 2^14, 8 + 6 -> 14:  batch 1 +18 %, 32 +8 %, 64 0 %, 128 -15 %, 256 -22 %, 1024..4096 -1 .. -3 %, 65536 -20 % (inverse -1 .. -22 %)
 #ifndef NTT_ALT_MIN_BATCH_GL13
-#define NTT_ALT_MIN_BATCH_GL13 1024   // 8-byte N = 2^13: one 13-stage pass from this batch on (two workgroups per CU: 512 in flight)
+#define NTT_ALT_MIN_BATCH_GL13 128    // 8-byte N = 2^13: one 13-stage pass from this batch on (512 threads, two workgroups per CU)
 #endif
 #ifndef NTT_ALT_MIN_BATCH_M32_14
-#define NTT_ALT_MIN_BATCH_M32_14 512  // 4-byte lazy primes, N = 2^14: one 14-stage pass (one 1024-thread workgroup per CU)
+#define NTT_ALT_MIN_BATCH_M32_14 128  // 4-byte lazy primes, N = 2^14: one 14-stage pass (one 1024-thread workgroup per CU)
 #endif
 
 inline std::vector<PlanAlt> plan_alternatives(int n, int word_bytes, uint64_t p) {
     std::vector<PlanAlt> alts;
     std::vector<PassDesc> def = plan_passes(n, word_bytes);
-    if (word_bytes == 4 && !m32_lazy_modulus(p) && n == 16) {
-        // carry-select / v_min streams (p >= 2^30): 8 + 8 beats 10 + 6 by 1.5 % (profiles/r02_split_sweep_final.txt); the
-        // lazy stream's lighter butterflies move the optimum to 10 + 6 (-7.2 %), which is plan_passes()'s table
-        def = {{true, 0, 8}, {false, 8, 8}};
-    }
+    // (4-byte N = 2^16 by modulus class, re-measured in round 3: 10 + 6 against 8 + 8 is -7.1 % for a lazy prime, -1.7 % for a
+    // 31-bit one and +0.2 % -- noise -- for a 32-bit one; at batch 1 all within 1 %: one split, plan_passes()'s, for all classes)
     alts.push_back({def, 0});
     if (word_bytes == 8 && n == 13) alts.push_back({{{true, 0, 13}}, NTT_ALT_MIN_BATCH_GL13});
     if (word_bytes == 4 && m32_lazy_modulus(p) && n == 14) alts.push_back({{{true, 0, 14}}, NTT_ALT_MIN_BATCH_M32_14});
