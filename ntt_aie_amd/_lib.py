@@ -54,8 +54,9 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def open_library(path: str) -> C.CDLL:
-    """dlopen one build of the C-ABI and declare its signatures (the product library, or tools' experiment build)."""
+def open_library(path: str, since_v3: bool = True) -> C.CDLL:
+    """dlopen one build of the C-ABI and declare its signatures (the product library, or tools' experiment build).
+    since_v3=False: an older build without the round-3 entry points (tools/regress_sweep.py times one against the tree)."""
     L = C.CDLL(path)
     vp, sz, u64 = C.c_void_p, C.c_size_t, C.c_uint64
     L.ntt_version.restype = C.c_int
@@ -71,9 +72,10 @@ def open_library(path: str) -> C.CDLL:
     L.ntt_plan_get_twiddles.argtypes = [vp, C.c_int, vp]
     L.ntt_plan_info.restype = C.c_int64
     L.ntt_plan_info.argtypes = [vp, C.c_int]
-    L.ntt_plan_select.argtypes = [vp, sz]
-    L.ntt_plan_set_policy.argtypes = [vp, C.c_int]
-    L.ntt_plan_clone.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    if since_v3:
+        L.ntt_plan_select.argtypes = [vp, sz]
+        L.ntt_plan_set_policy.argtypes = [vp, C.c_int]
+        L.ntt_plan_clone.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.ntt_forward.argtypes = [vp, vp, vp, sz, C.c_int, vp]
     L.ntt_forward_profile.argtypes = [vp, vp, vp, sz, C.c_int, vp, C.POINTER(C.c_float), C.c_int,
                                       C.POINTER(C.c_int)]

@@ -8,6 +8,9 @@
 //   FieldM32 : 4-byte words, any odd p < 2^32.  Twiddles are kept in Montgomery
 //              form (T * 2^32 mod p) so one product costs v_mad_u64_u32 +
 //              v_mul_lo_u32 + v_mul_hi_u32 and returns the canonical x*T mod p.
+//   FieldM64 : 8-byte words, ANY odd p < 2^64 (the reference's `%`-based network works for any modulus, src/test.cpp:48-50;
+//              BASELINE's metric says "64-bit prime").  Montgomery with R = 2^64: eleven 32-bit multiplies per
+//              product where the Goldilocks reduction needs four -- the general path, not the headline one.
 //   FieldGL  : 8-byte words, p = 2^64 - 2^32 + 1.  Twiddles in Montgomery form
 //              (T * 2^64 mod p); 64x64->128 product from four v_mad_u64_u32, then the
 //              shift/add Montgomery reduction special to this prime.
@@ -51,6 +54,36 @@ struct FieldM32 {
         return (hi < mh) ? r + p : r;
     }
     // plain x*y mod p for two normal-form operands
+    NTT_HD W mul_plain(W x, W y) const { return mul(mul(x, y), r2); }
+    NTT_HD W to_table_form(W t) const { return mul(t, r2); }
+};
+
+struct FieldM64 {
+    using W = uint64_t;
+    uint64_t p;     // modulus (odd, < 2^64)
+    uint64_t pinv;  // p^-1 mod 2^64
+    uint64_t r2;    // 2^128 mod p (to enter Montgomery form)
+
+    NTT_HD W add(W a, W b) const {
+        const uint64_t s = a + b;  // may wrap when p > 2^63: keep the carry
+        const bool carry = s < a;
+        return (carry || s >= p) ? s - p : s;
+    }
+    NTT_HD W sub(W a, W b) const {
+        const uint64_t d = a - b;
+        return (a < b) ? d + p : d;
+    }
+    // x any 64-bit word, tw = T * 2^64 mod p (Montgomery form, < p)  ->  x*T mod p, canonical:
+    //   t = x * tw < 2^64 * p;  m = lo(t) * p^-1 mod 2^64;  m*p has the same low half as t, so
+    //   (t - m*p) / 2^64 = hi(t) - hi(m*p)  in (-p, p)
+    NTT_HD W mul(W x, W tw) const {
+        const unsigned __int128 t = (unsigned __int128) x * tw;
+        const uint64_t lo = (uint64_t) t, hi = (uint64_t) (t >> 64);
+        const uint64_t m = lo * pinv;
+        const uint64_t mh = (uint64_t) (((unsigned __int128) m * p) >> 64);
+        const uint64_t r = hi - mh;
+        return (hi < mh) ? r + p : r;
+    }
     NTT_HD W mul_plain(W x, W y) const { return mul(mul(x, y), r2); }
     NTT_HD W to_table_form(W t) const { return mul(t, r2); }
 };

@@ -14,6 +14,7 @@ struct ErasedArgs {
     const void *tw;
     const void *tw_sc;     // scaled inverse, Goldilocks CONTIG pass: stage-0 twiddles * N^-1 (PassArgs::tw_sc); null = phase_scale
     uint32_t p, pinv, r2;  // FieldM32 parameters (ignored by FieldGL)
+    uint64_t p64, pinv64, r2_64;  // FieldM64 parameters (general odd 64-bit modulus)
     int n, s0;
     uint32_t batch;
     int layout;
@@ -33,6 +34,8 @@ hipError_t launch_gl_fwd(bool contig, int log_m, const ErasedArgs &a, hipStream_
 hipError_t launch_gl_inv(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
 hipError_t launch_m32_fwd(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
 hipError_t launch_m32_inv(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
+hipError_t launch_m64_fwd(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);  // any odd p < 2^64 (FieldM64)
+hipError_t launch_m64_inv(bool contig, int log_m, const ErasedArgs &a, hipStream_t s);
 
 // Fused middle of a negacyclic product (pass.h: run_product_pass): per 2^log_m-word unit, inverse CONTIG pass of a.in
 // and of a.in2, word-by-word product * pw_scale, forward CONTIG pass -> a.out.  tw = inverse table, tw2 = forward table.
@@ -60,11 +63,15 @@ hipError_t launch_pointwise_gl(const void *a, const void *b, void *c, size_t cou
                                hipStream_t s);
 hipError_t launch_pointwise_m32(const void *a, const void *b, void *c, size_t count, uint32_t p,
                                 uint32_t pinv, uint32_t r2, uint32_t scale, hipStream_t s);
+hipError_t launch_pointwise_m64(const void *a, const void *b, void *c, size_t count, uint64_t p,
+                                uint64_t pinv, uint64_t r2, uint64_t scale, hipStream_t s);
 
 // device-side table generation (no host upload): T[i] = base^e_kind(i), table form
 hipError_t launch_gen_table_gl(void *T, int logn, int kind, uint64_t base_m, uint64_t one_m, hipStream_t s);
 hipError_t launch_gen_table_m32(void *T, int logn, int kind, uint32_t base_m, uint32_t one_m, uint32_t p,
                                 uint32_t pinv, uint32_t r2, hipStream_t s);
+hipError_t launch_gen_table_m64(void *T, int logn, int kind, uint64_t base_m, uint64_t one_m, uint64_t p,
+                                uint64_t pinv, uint64_t r2, hipStream_t s);
 
 // out[i] = T[i] * c (table form both): the N/2 scaled stage-0 twiddles of the Goldilocks inverse transform
 hipError_t launch_scale_table_gl(const void *T, void *out, size_t count, uint64_t c_m, hipStream_t s);
@@ -76,5 +83,7 @@ hipError_t launch_count_noncanonical(const void *a, size_t count, int word_bytes
 hipError_t launch_stage_gl(void *data, const void *tw, int n, int stage, size_t batch, hipStream_t s);
 hipError_t launch_stage_m32(void *data, const void *tw, int n, int stage, size_t batch, uint32_t p,
                             uint32_t pinv, uint32_t r2, hipStream_t s);
+hipError_t launch_stage_m64(void *data, const void *tw, int n, int stage, size_t batch, uint64_t p,
+                            uint64_t pinv, uint64_t r2, hipStream_t s);
 
 }  // namespace ntt

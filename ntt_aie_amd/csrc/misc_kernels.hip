@@ -182,6 +182,15 @@ hipError_t launch_pointwise_m32(const void *a, const void *b, void *c, size_t co
     return hipGetLastError();
 }
 
+hipError_t launch_pointwise_m64(const void *a, const void *b, void *c, size_t count, uint64_t p,
+                                uint64_t pinv, uint64_t r2, uint64_t scale, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(pointwise_kernel<FieldM64>, dim3(grid_for(count / 2)), dim3(256), 0, s,
+                       (const uint64_t *) a, (const uint64_t *) b, (uint64_t *) c, count,
+                       FieldM64{p, pinv, r2}, scale, scale != 1 ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_gen_table_gl(void *T, int logn, int kind, uint64_t base_m, uint64_t one_m, hipStream_t s) {
     hipLaunchKernelGGL(gen_table_kernel<FieldGL>, dim3(grid_for((size_t) 1 << logn)), dim3(256), 0, s,
                        (uint64_t *) T, logn, kind, base_m, one_m, FieldGL{});
@@ -192,6 +201,13 @@ hipError_t launch_gen_table_m32(void *T, int logn, int kind, uint32_t base_m, ui
                                 uint32_t pinv, uint32_t r2, hipStream_t s) {
     hipLaunchKernelGGL(gen_table_kernel<FieldM32>, dim3(grid_for((size_t) 1 << logn)), dim3(256), 0, s,
                        (uint32_t *) T, logn, kind, base_m, one_m, FieldM32{p, pinv, r2});
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_table_m64(void *T, int logn, int kind, uint64_t base_m, uint64_t one_m, uint64_t p,
+                                uint64_t pinv, uint64_t r2, hipStream_t s) {
+    hipLaunchKernelGGL(gen_table_kernel<FieldM64>, dim3(grid_for((size_t) 1 << logn)), dim3(256), 0, s,
+                       (uint64_t *) T, logn, kind, base_m, one_m, FieldM64{p, pinv, r2});
     return hipGetLastError();
 }
 
@@ -226,6 +242,15 @@ hipError_t launch_stage_m32(void *data, const void *tw, int n, int stage, size_t
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(stage_kernel<FieldM32>, dim3(grid_for(total)), dim3(256), 0, s, (uint32_t *) data,
                        (const uint32_t *) tw, n, stage, total, FieldM32{p, pinv, r2});
+    return hipGetLastError();
+}
+
+hipError_t launch_stage_m64(void *data, const void *tw, int n, int stage, size_t batch, uint64_t p,
+                            uint64_t pinv, uint64_t r2, hipStream_t s) {
+    const size_t total = batch << (n - 1);
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(stage_kernel<FieldM64>, dim3(grid_for(total)), dim3(256), 0, s, (uint64_t *) data,
+                       (const uint64_t *) tw, n, stage, total, FieldM64{p, pinv, r2});
     return hipGetLastError();
 }
 

@@ -80,8 +80,11 @@ struct ntt_plan {
     uint64_t p;
     int word_bytes;
     int device;
+    int fk;  // arithmetic: FK_M32 (4-byte words), FK_GL (p = 2^64 - 2^32 + 1), FK_M64 (any other odd 8-byte modulus)
     // FieldM32 parameters
     uint32_t pinv, r2;
+    // FieldM64 parameters
+    uint64_t pinv64, r2_64;
     // device tables, table form
     void *d_tw_fwd;
     void *d_tw_inv;
@@ -105,8 +108,21 @@ struct ntt_plan {
 
 namespace {
 
+enum { FK_M32 = 0, FK_GL = 1, FK_M64 = 2 };
+
+hipError_t launch_fwd(const ntt_plan *pl, const PassDesc &pd, const ntt::ErasedArgs &a, hipStream_t s) {
+    return pl->fk == FK_GL ? ntt::launch_gl_fwd(pd.contig, pd.log_m, a, s)
+         : pl->fk == FK_M64 ? ntt::launch_m64_fwd(pd.contig, pd.log_m, a, s)
+                            : ntt::launch_m32_fwd(pd.contig, pd.log_m, a, s);
+}
+hipError_t launch_inv(const ntt_plan *pl, const PassDesc &pd, const ntt::ErasedArgs &a, hipStream_t s) {
+    return pl->fk == FK_GL ? ntt::launch_gl_inv(pd.contig, pd.log_m, a, s)
+         : pl->fk == FK_M64 ? ntt::launch_m64_inv(pd.contig, pd.log_m, a, s)
+                            : ntt::launch_m32_inv(pd.contig, pd.log_m, a, s);
+}
+
 size_t table_bytes(const ntt_plan *pl) { return ((size_t) 1 << pl->logn) * pl->word_bytes; }
-size_t sc_table_bytes(const ntt_plan *pl) { return pl->word_bytes == 8 ? table_bytes(pl) / 2 : 0; }
+size_t sc_table_bytes(const ntt_plan *pl) { return pl->fk == FK_GL ? table_bytes(pl) / 2 : 0; }
 
 // the decomposition the launchers run for this batch
 const std::vector<PassDesc> &passes_for(const ntt_plan *pl, size_t batch) {
@@ -122,6 +138,9 @@ ntt::ErasedArgs base_args(const ntt_plan *pl, const PassDesc &pd, const void *in
     a.p = (uint32_t) pl->p;
     a.pinv = pl->pinv;
     a.r2 = pl->r2;
+    a.p64 = pl->p;
+    a.pinv64 = pl->pinv64;
+    a.r2_64 = pl->r2_64;
     a.n = pl->logn;
     a.s0 = pd.s0;
     a.batch = (uint32_t) batch;
@@ -172,8 +191,7 @@ int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
         }
         a.tw = pl->d_tw_fwd;
         a.layout = layout;
-        hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_fwd(pd.contig, pd.log_m, a, s)
-                                           : ntt::launch_m32_fwd(pd.contig, pd.log_m, a, s);
+        hipError_t e = launch_fwd(pl, pd, a, s);
         if (e != hipSuccess) return (int) e;
         src = d_out;
     }
@@ -195,8 +213,7 @@ int run_inverse(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
         a.scale = pl->scale_tf;
         // Goldilocks: N^-1 rides on the last executed stage (stage 0 of the CONTIG pass) instead of a sweep over the outputs
         a.tw_sc = a.do_scale ? pl->d_tw_inv_sc : nullptr;
-        hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_inv(pd.contig, pd.log_m, a, s)
-                                           : ntt::launch_m32_inv(pd.contig, pd.log_m, a, s);
+        hipError_t e = launch_inv(pl, pd, a, s);
         if (e != hipSuccess) return (int) e;
         src = d_out;
     }
@@ -224,7 +241,7 @@ const char *ntt_error_string(int code) {
     switch (code) {
         case NTT_OK: return "ok";
         case NTT_E_ARG: return "invalid argument (null / misaligned pointer, size out of range)";
-        case NTT_E_PRIME: return "unsupported modulus for this word size";
+        case NTT_E_PRIME: return "unsupported modulus for this word size (must be odd, >= 3, and < 2^32 for 4-byte words)";
         case NTT_E_LOGN: return "logn out of range";
         case NTT_E_NOTABLE: return "twiddle table not set";
         case NTT_E_NOTINVERTIBLE: return "twiddle table has an entry that is not a unit mod p";
@@ -248,11 +265,8 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     *out = nullptr;
     if (word_bytes != 4 && word_bytes != 8) return NTT_E_ARG;
     if (logn < 1 || logn > NTT_MAX_LOGN) return NTT_E_LOGN;
-    if (word_bytes == 8) {
-        if (p != GOLDILOCKS) return NTT_E_PRIME;
-    } else {
-        if ((p & 1) == 0 || p < 3 || p > 0xFFFFFFFFull) return NTT_E_PRIME;
-    }
+    if ((p & 1) == 0 || p < 3) return NTT_E_PRIME;
+    if (word_bytes == 4 && p > 0xFFFFFFFFull) return NTT_E_PRIME;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return NTT_E_NODEVICE;
     ntt_plan *pl = new (std::nothrow) ntt_plan();
@@ -264,11 +278,16 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     pl->d_tw_fwd = pl->d_tw_inv = pl->d_tw_inv_sc = nullptr;
     pl->has_table = pl->has_inv = false;
     pl->pinv = pl->r2 = 0;
-    if (word_bytes == 4) {
+    pl->pinv64 = pl->r2_64 = 0;
+    pl->fk = word_bytes == 4 ? FK_M32 : (p == GOLDILOCKS ? FK_GL : FK_M64);
+    if (pl->fk == FK_M32) {
         pl->pinv = mont_pinv((uint32_t) p);
         pl->r2 = mont_r2((uint32_t) p);
+    } else if (pl->fk == FK_M64) {
+        pl->pinv64 = mont_pinv64(p);
+        pl->r2_64 = mont_r2_64(p);
     }
-    pl->ninv_plain = powmod((p + 1) / 2, (uint64_t) logn, p);  // (2^-1)^logn; p + 1 < 2^64
+    pl->ninv_plain = powmod(p / 2 + 1, (uint64_t) logn, p);  // (2^-1)^logn; 2^-1 = (p + 1) / 2 = p / 2 + 1 for odd p (no overflow at p near 2^64)
     pl->scale_tf = to_table_form(pl->ninv_plain, p, word_bytes);
     pl->target_wgs = 8192;  // workgroups per launch the batch loop is sized for (sweep: profiles/)
     // column passes: 16384 (their tile streams 8 polynomials per workgroup at N = 2^16, batch 4096, instead of 16): -4 %
@@ -425,7 +444,11 @@ int ntt_plan_generate_twiddles(ntt_plan_t pl, int kind, uint64_t g) {
     DeviceGuard g_(pl->device);
     if (g_.err != hipSuccess) return (int) g_.err;
     hipError_t e;
-    if (wb == 8) {
+    if (pl->fk == FK_M64) {
+        e = ntt::launch_gen_table_m64(pl->d_tw_fwd, pl->logn, kind, to_table_form(base, p, 8), one_m, p, pl->pinv64, pl->r2_64, nullptr);
+        if (e == hipSuccess)
+            e = ntt::launch_gen_table_m64(pl->d_tw_inv, pl->logn, kind, to_table_form(base_inv, p, 8), one_m, p, pl->pinv64, pl->r2_64, nullptr);
+    } else if (wb == 8) {
         e = ntt::launch_gen_table_gl(pl->d_tw_fwd, pl->logn, kind, to_table_form(base, p, 8), one_m, nullptr);
         if (e == hipSuccess)
             e = ntt::launch_gen_table_gl(pl->d_tw_inv, pl->logn, kind, to_table_form(base_inv, p, 8), one_m, nullptr);
@@ -595,8 +618,7 @@ int ntt_forward_profile(ntt_plan_t pl, const void *d_in, void *d_out, size_t bat
         ntt::ErasedArgs a = base_args(pl, pd, src, d_out, batch);
         a.tw = pl->d_tw_fwd;
         a.layout = out_layout;
-        e = pl->word_bytes == 8 ? ntt::launch_gl_fwd(pd.contig, pd.log_m, a, s)
-                                : ntt::launch_m32_fwd(pd.contig, pd.log_m, a, s);
+        e = launch_fwd(pl, pd, a, s);
         if (e == hipSuccess) e = hipEventRecord(ev[i + 1], s);
         src = d_out;
     }
@@ -630,10 +652,11 @@ int ntt_pointwise_mul(ntt_plan_t pl, const void *d_a, const void *d_b, void *d_o
     DeviceGuard g(pl->device);
     if (g.err != hipSuccess) return (int) g.err;
     const size_t count = batch << pl->logn;
-    hipError_t e = pl->word_bytes == 8
-                       ? ntt::launch_pointwise_gl(d_a, d_b, d_out, count, scale, (hipStream_t) stream)
-                       : ntt::launch_pointwise_m32(d_a, d_b, d_out, count, (uint32_t) pl->p, pl->pinv,
-                                                   pl->r2, (uint32_t) scale, (hipStream_t) stream);
+    hipError_t e = pl->fk == FK_GL    ? ntt::launch_pointwise_gl(d_a, d_b, d_out, count, scale, (hipStream_t) stream)
+                   : pl->fk == FK_M64 ? ntt::launch_pointwise_m64(d_a, d_b, d_out, count, pl->p, pl->pinv64, pl->r2_64, scale,
+                                                                  (hipStream_t) stream)
+                                      : ntt::launch_pointwise_m32(d_a, d_b, d_out, count, (uint32_t) pl->p, pl->pinv,
+                                                                  pl->r2, (uint32_t) scale, (hipStream_t) stream);
     return (int) e;
 }
 
@@ -657,12 +680,13 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
     // Goldilocks, first (or only) pass of 7..12 stages: the radix-8 product kernel exists for that unit size.  A single-pass
     // size (2^7 <= N <= 2^12) is then ONE launch for the whole product: read a, read b, write c.
     // ... 4-byte words: radix-16 product kernel, unit sizes 2^6 .. 2^13 (any odd p: all three butterfly streams).
-    bool fused_mid = first.contig && (pl->word_bytes == 8 ? ntt::have_gl_product_mid(first.log_m)
-                                                           : ntt::have_m32_product_mid(first.log_m));
+    // (the general 64-bit modulus has no product kernel: separate passes, pointwise product folded into the first forward pass)
+    bool fused_mid = first.contig && pl->fk != FK_M64 && (pl->fk == FK_GL ? ntt::have_gl_product_mid(first.log_m)
+                                                                          : ntt::have_m32_product_mid(first.log_m));
     if (fused_mid) {
         // the product launch is not sliced: beyond blockIdx.y's range (tens of millions of tiny polynomials) take the
         // separate passes, whose launcher slices the batch.  The check IS the launcher's geometry call (product_fits).
-        fused_mid = pl->word_bytes == 8 ? ntt::gl_product_mid_fits(first.log_m, pl->logn, (uint32_t) batch, pl->target_wgs)
+        fused_mid = pl->fk == FK_GL ? ntt::gl_product_mid_fits(first.log_m, pl->logn, (uint32_t) batch, pl->target_wgs)
                                         : ntt::m32_product_mid_fits(first.log_m, pl->logn, (uint32_t) batch, pl->target_wgs);
     }
     if (fused_mid) {
@@ -678,8 +702,7 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
                 ntt::ErasedArgs a = base_args(pl, pd, buf, buf, contiguous ? 2 * batch : batch);
                 a.tw = pl->d_tw_inv;
                 a.layout = NTT_LAYOUT_NATURAL;
-                hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_inv(pd.contig, pd.log_m, a, s)
-                                                   : ntt::launch_m32_inv(pd.contig, pd.log_m, a, s);
+                hipError_t e = launch_inv(pl, pd, a, s);
                 if (e != hipSuccess) return (int) e;
             }
         }
@@ -691,7 +714,7 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
             a.tw2 = pl->d_tw_fwd;
             a.layout = NTT_LAYOUT_NATURAL;
             a.pw_scale = to_table_form(to_table_form(pl->ninv_plain % pl->p, pl->p, pl->word_bytes), pl->p, pl->word_bytes);
-            hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_product_mid(first.log_m, a, s)
+            hipError_t e = pl->fk == FK_GL ? ntt::launch_gl_product_mid(first.log_m, a, s)
                                                : ntt::launch_m32_product_mid(first.log_m, a, s);
             if (e != hipSuccess) return (int) e;
         }
@@ -701,8 +724,7 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
             ntt::ErasedArgs a = base_args(pl, pd, d_out, d_out, batch);
             a.tw = pl->d_tw_fwd;
             a.layout = NTT_LAYOUT_NATURAL;
-            hipError_t e = pl->word_bytes == 8 ? ntt::launch_gl_fwd(pd.contig, pd.log_m, a, s)
-                                               : ntt::launch_m32_fwd(pd.contig, pd.log_m, a, s);
+            hipError_t e = launch_fwd(pl, pd, a, s);
             if (e != hipSuccess) return (int) e;
         }
         return NTT_OK;
@@ -753,10 +775,10 @@ int ntt_forward_stages(ntt_plan_t pl, const void *d_in, void *d_out, size_t batc
         if (e != hipSuccess) return (int) e;
     }
     for (int st = 0; st <= stage; st++) {
-        hipError_t e = pl->word_bytes == 8
-                           ? ntt::launch_stage_gl(d_out, pl->d_tw_fwd, pl->logn, st, batch, s)
-                           : ntt::launch_stage_m32(d_out, pl->d_tw_fwd, pl->logn, st, batch,
-                                                   (uint32_t) pl->p, pl->pinv, pl->r2, s);
+        hipError_t e = pl->fk == FK_GL    ? ntt::launch_stage_gl(d_out, pl->d_tw_fwd, pl->logn, st, batch, s)
+                       : pl->fk == FK_M64 ? ntt::launch_stage_m64(d_out, pl->d_tw_fwd, pl->logn, st, batch, pl->p, pl->pinv64, pl->r2_64, s)
+                                          : ntt::launch_stage_m32(d_out, pl->d_tw_fwd, pl->logn, st, batch,
+                                                                  (uint32_t) pl->p, pl->pinv, pl->r2, s);
         if (e != hipSuccess) return (int) e;
     }
     return NTT_OK;

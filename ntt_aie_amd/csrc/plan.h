@@ -165,6 +165,16 @@ inline uint32_t mont_pinv(uint32_t p) {
     return inv;
 }
 inline uint32_t mont_r2(uint32_t p) { return (uint32_t) ((((u128) 1) << 64) % p); }
+// ... and of FieldM64 (R = 2^64)
+inline uint64_t mont_pinv64(uint64_t p) {
+    uint64_t inv = p;
+    for (int i = 0; i < 6; i++) inv *= 2ull - p * inv;
+    return inv;
+}
+inline uint64_t mont_r2_64(uint64_t p) {
+    const uint64_t r = (uint64_t) ((((u128) 1) << 64) % p);  // 2^64 mod p
+    return mulmod(r, r, p);
+}
 
 // value -> the form the kernels keep twiddles in
 inline uint64_t to_table_form(uint64_t t, uint64_t p, int word_bytes) {

@@ -141,6 +141,7 @@ struct Erased {
     const void *tw;
     const void *tw_sc;  // Goldilocks scaled inverse: stage-0 twiddles * N^-1 (N/2 words), as ntt_api.hip prepares them
     uint32_t p, pinv, r2;
+    uint64_t p64, pinv64, r2_64;  // FieldM64
     int n, s0;
     uint32_t batch;
     int layout, do_scale;
@@ -159,6 +160,10 @@ FieldGL make_field<FieldGL>(const Erased &) {
 template <>
 FieldM32 make_field<FieldM32>(const Erased &e) {
     return FieldM32{e.p, e.pinv, e.r2};
+}
+template <>
+FieldM64 make_field<FieldM64>(const Erased &e) {
+    return FieldM64{e.p64, e.pinv64, e.r2_64};
 }
 
 template <class PC>
@@ -352,8 +357,8 @@ int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, con
         tw = t64.data();
     }
     std::vector<uint64_t> tsc;  // stage-0 twiddles of the scaled Goldilocks inverse, as ntt_plan_set_twiddles makes them
-    if (inverse && word_bytes == 8) {
-        const uint64_t ninv = powmod((p + 1) / 2, (uint64_t) logn, p);
+    if (inverse && word_bytes == 8 && p == GOLDILOCKS) {
+        const uint64_t ninv = powmod(p / 2 + 1, (uint64_t) logn, p);
         tsc.resize(N / 2);
         for (size_t i = 0; i < N / 2; i++) tsc[i] = to_table_form(mulmod(Ti[N / 2 + i], ninv, p), p, 8);
     }
@@ -378,13 +383,19 @@ int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, con
         e.pinv = mont_pinv((uint32_t) p);
         e.r2 = mont_r2((uint32_t) p);
     }
+    const bool m64 = word_bytes == 8 && p != GOLDILOCKS;  // general odd 64-bit modulus (ntt_api.hip: FK_M64)
+    e.p64 = p;
+    if (m64) {
+        e.pinv64 = mont_pinv64(p);
+        e.r2_64 = mont_r2_64(p);
+    }
     e.n = logn;
     e.batch = batch;
     e.layout = layout;
     e.target_wgs = target_wgs;
     e.tw = tw;
     e.tw_sc = tsc.empty() ? nullptr : tsc.data();
-    e.scale = to_table_form(powmod((p + 1) / 2, (uint64_t) logn, p), p, word_bytes);
+    e.scale = to_table_form(powmod(p / 2 + 1, (uint64_t) logn, p), p, word_bytes);
     const void *cur = in;
     const size_t np = passes.size();
     for (size_t k = 0; k < np; k++) {
@@ -394,7 +405,10 @@ int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, con
         e.s0 = passes[i].s0;
         e.do_scale = (inverse && scale && i == 0) ? 1 : 0;
         int rc;
-        if (word_bytes == 8)
+        if (m64)
+            rc = inverse ? dispatch<FieldM64, true>(passes[i].contig, passes[i].log_m, e)
+                         : dispatch<FieldM64, false>(passes[i].contig, passes[i].log_m, e);
+        else if (word_bytes == 8)
             rc = inverse ? dispatch<FieldGL, true>(passes[i].contig, passes[i].log_m, e)
                          : dispatch<FieldGL, false>(passes[i].contig, passes[i].log_m, e);
         else
@@ -577,6 +591,13 @@ int emu_geometry(int n, int s0, int log_m, int log_c, int log_u, int contig, uin
 uint64_t emu_gl_mul(uint64_t a, uint64_t b) { return FieldGL{}.mul_plain(a, b); }
 uint64_t emu_gl_add(uint64_t a, uint64_t b) { return FieldGL{}.add(a, b); }
 uint64_t emu_gl_sub(uint64_t a, uint64_t b) { return FieldGL{}.sub(a, b); }
+uint64_t emu_m64_mul_plain(uint64_t a, uint64_t b, uint64_t p) {
+    FieldM64 f{p, mont_pinv64(p), mont_r2_64(p)};
+    return f.mul_plain(a, b);
+}
+uint64_t emu_m64_mul(uint64_t x, uint64_t tw, uint64_t p) { return FieldM64{p, mont_pinv64(p), mont_r2_64(p)}.mul(x, tw); }
+uint64_t emu_m64_add(uint64_t a, uint64_t b, uint64_t p) { return FieldM64{p, 0, 0}.add(a, b); }
+uint64_t emu_m64_sub(uint64_t a, uint64_t b, uint64_t p) { return FieldM64{p, 0, 0}.sub(a, b); }
 uint32_t emu_m32_mul_plain(uint32_t a, uint32_t b, uint32_t p) {
     FieldM32 f{p, mont_pinv(p), mont_r2(p)};
     return f.mul_plain(a, b);

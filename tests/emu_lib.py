@@ -28,6 +28,9 @@ def lib():
         for n in ("emu_gl_mul", "emu_gl_add", "emu_gl_sub"):
             getattr(L, n).restype = C.c_uint64
             getattr(L, n).argtypes = [C.c_uint64, C.c_uint64]
+        for n in ("emu_m64_mul_plain", "emu_m64_mul", "emu_m64_add", "emu_m64_sub"):
+            getattr(L, n).restype = C.c_uint64
+            getattr(L, n).argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         for n in ("emu_m32_mul_plain", "emu_m32_add", "emu_m32_sub"):
             getattr(L, n).restype = C.c_uint32
             getattr(L, n).argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]

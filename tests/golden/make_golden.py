@@ -9,8 +9,10 @@ Two independent sources, both committed as plain integer arrays:
                   Valid for p <= 46340.  Needs /root/reference.
   bigint_*.npz    produced by an independent pure-Python big-int restatement of
                   the same network (this file, `net_forward`), for primes outside
-                  the literal code's int32 window: 998244353, 3221225473 and the
-                  Goldilocks prime 2^64-2^32+1.
+                  the literal code's int32 window: 998244353, 3221225473, the
+                  Goldilocks prime 2^64-2^32+1, and (round 3, general 64-bit modulus)
+                  the 62-bit NTT prime 0x3fffffee00000001 (g = 3) and the 64-bit one
+                  0xfffffffc00000001 (g = 10, above 2^63: sums carry out of the word).
 
 Run from the repo root:  python tests/golden/make_golden.py
 """
@@ -24,6 +26,8 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 GOLD = 0xFFFFFFFF00000001
+P62 = 0x3FFFFFEE00000001   # 4611685941117976577 = 0x3fffffee * 2^32 + 1, prime, primitive root 3
+P64B = 0xFFFFFFFC00000001  # 18446744056529682433 = 0xfffffffc * 2^32 + 1, prime, primitive root 10
 
 
 def splitmix64(x):
@@ -104,10 +108,13 @@ def literal():
         barrett=np.array([R.ref_barrett_2k(int(a), int(b), q, w, u) for a, b in ab], dtype=np.int32))
 
 
-def bigint():
+def bigint(only_new=False):
     cases = [(64, 998244353, 3, 4), (1024, 998244353, 3, 4), (256, 3221225473, 5, 4),
-             (64, GOLD, 7, 8), (1024, GOLD, 7, 8), (4096, GOLD, 7, 8)]
+             (64, GOLD, 7, 8), (1024, GOLD, 7, 8), (4096, GOLD, 7, 8),
+             (64, P62, 3, 8), (4096, P62, 3, 8), (1024, P64B, 10, 8)]
     for n, p, g, wb in cases:
+        if only_new and os.path.exists(os.path.join(HERE, "bigint_n%d_p%d.npz" % (n, p))):
+            continue
         dt = np.uint32 if wb == 4 else np.uint64
         T = roots_rule(n, p, g)
         a = rand_poly(n, p, 77 * n + wb)
@@ -121,5 +128,8 @@ def bigint():
 
 
 if __name__ == "__main__":
-    literal()
-    bigint()
+    if "--only-new" in sys.argv:  # add fixtures that do not exist yet, leave the committed ones byte-identical
+        bigint(only_new=True)
+    else:
+        literal()
+        bigint()

@@ -43,7 +43,8 @@ def test_error_contract_without_compute(hiplib):
     assert L.ntt_plan_create(C.byref(h), 0, 3329, 4, 0) == hiplib.NTT_E_LOGN
     assert L.ntt_plan_create(C.byref(h), 29, 3329, 4, 0) == hiplib.NTT_E_LOGN
     assert L.ntt_plan_create(C.byref(h), 8, 3330, 4, 0) == hiplib.NTT_E_PRIME
-    assert L.ntt_plan_create(C.byref(h), 8, 3329, 8, 0) == hiplib.NTT_E_PRIME
+    assert L.ntt_plan_create(C.byref(h), 8, 1 << 40, 8, 0) == hiplib.NTT_E_PRIME   # even modulus, 8-byte words
+    assert L.ntt_plan_create(C.byref(h), 8, 1, 8, 0) == hiplib.NTT_E_PRIME
     assert L.ntt_plan_create(C.byref(h), 8, (1 << 32) + 15, 4, 0) == hiplib.NTT_E_PRIME
     assert L.ntt_forward(None, None, None, 1, 0, None) == hiplib.NTT_E_ARG
     assert L.ntt_plan_destroy(None) == hiplib.NTT_E_ARG

@@ -254,3 +254,42 @@ def test_tapered_rows_cover_every_polynomial_group_once():
     assert L.emu_geometry(16, 8, 8, 4, 0, 0, 4096, 16384, 4, out) == 0
     assert list(out)[:3] == [4, 16, 1536] and list(out)[4:] == [768, 256, 512, 0]  # its column pass: ppw 4, 2, 1
     assert L.emu_geometry(8, 0, 8, 0, 4, 1, 1 << 30, 8192, 64, out) == 0 and out[5] == 0  # beyond blockIdx.y: no taper, sliced
+
+
+P62, P64B = 0x3FFFFFEE00000001, 0xFFFFFFFC00000001  # general odd 64-bit moduli (FieldM64): below 2^62 / above 2^63
+
+
+def test_general_64bit_modulus_field_edges():
+    """FieldM64 (Montgomery, R = 2^64) against Python integers: edge residues of a 62-bit prime, of a prime above 2^63 (sums
+    carry out of the word), of Goldilocks itself taken through the general path, and of a small composite odd modulus."""
+    L = emu_lib.lib()
+    rng = np.random.default_rng(3)
+    for p in (P62, P64B, GOLD, 0xFFFFFFFFFFFFFFC5, 3329, 3):  # 2^64 - 59: the largest 64-bit prime
+        r = (1 << 64) % p
+        edge = sorted({0, 1, 2 % p, p - 1, p - 2, p // 2, p // 2 + 1, (1 << 32) % p, ((1 << 32) - 1) % p, ((1 << 63) - 1) % p, (1 << 63) % p})
+        vals = edge + [int(x) % p for x in rng.integers(0, 2**63, size=24, dtype=np.uint64) * 2 + 1]
+        for a in vals:
+            for b in vals:
+                assert L.emu_m64_mul_plain(a, b, p) == a * b % p, (p, a, b)
+                assert L.emu_m64_add(a, b, p) == (a + b) % p
+                assert L.emu_m64_sub(a, b, p) == (a - b) % p
+        # one Montgomery product with ANY 64-bit multiplicand (lazy inputs are legal for the multiplied operand)
+        rinv = pow(1 << 64, -1, p)
+        for x in (0, 1, p, p + 1 if p + 1 < 1 << 64 else p, (1 << 64) - 1, (1 << 63) + 12345):
+            for tw in edge:
+                assert L.emu_m64_mul(x, tw, p) == x * tw * rinv % p, (p, x, tw)
+
+
+@pytest.mark.parametrize("p,g", [(P62, 3), (P64B, 10)])
+def test_general_64bit_modulus_every_shape(oracle, p, g):
+    """The pass kernels instantiated for FieldM64 through the host model: single-pass sizes, the planner's multi-pass splits,
+    the 13-stage and 9-stage-column shapes, forward / inverse (scaled by phase_scale: the fold is a Goldilocks specialisation)."""
+    for logn in (1, 2, 3, 4, 6, 9, 12):
+        for inv in (0, 1):
+            _run(oracle, 8, logn, p, g, 5, inverse=inv, layout=int(logn >= 4), seed=logn)
+    for logn in (13, 16, 17):
+        for inv in (0, 1):
+            _run(oracle, 8, logn, p, g, 3, inverse=inv, layout=1, tw=8, seed=logn, inplace=True)
+    for ov in ((13,), (8, 9), (10, 6), (5, 4), (12, 4)):
+        for inv in (0, 1):
+            _run(oracle, 8, sum(ov), p, g, 2, inverse=inv, scale=inv, tw=4, ov=emu_lib.pack_passes(*ov), seed=11)

@@ -289,3 +289,74 @@ def test_bench_self_launch_refuses_missing_devices():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 2 and "only" in out.stderr and "device" in out.stderr and "{" not in out.stdout
+
+
+P62, P64B = 0x3FFFFFEE00000001, 0xFFFFFFFC00000001  # general odd 64-bit moduli: a 62-bit NTT prime (g = 3), one above 2^63 (g = 10)
+
+
+@pytest.mark.parametrize("p,g", [(P62, 3), (P64B, 10)])
+def test_general_64bit_modulus(eng, oracle, p, g):
+    """ntt_plan_create(..., word_bytes = 8, any odd p): FieldM64 (Montgomery, R = 2^64) behind the same passes -- BASELINE's
+    metric says "64-bit prime", the reference's `%`-based network takes any modulus (src/test.cpp:48-50).  N = 2^12 (one pass)
+    and 2^16 (two), every leg; tables made on the host and on the device; the product; the test_stage hook."""
+    dt = np.uint64
+    for logn in (12, 16):
+        n = 1 << logn
+        T = oracle.make_roots(n, p, g, 8)
+        pl = eng.NTTPlan(logn, p, 8, 0)
+        assert np.array_equal(pl.make_roots(g), T)
+        pl.set_twiddles(T)
+        _check_all_legs(eng, oracle, pl, T, p, dt, (1, 5), seed=logn)
+        pl2 = eng.NTTPlan(logn, p, 8, 0)
+        pl2.generate_twiddles(0, g)
+        assert np.array_equal(pl2.get_twiddles(), T)
+        a = _rand(3, n, p, dt, 77)
+        a[0, :4] = np.array([0, 1, p - 1, p - 2], dtype=dt)
+        f = pl2.forward(eng.to_device(a, "cuda:0"))
+        assert np.array_equal(eng.to_host(f), oracle.ntt(a, T, p, nthreads=4))
+        assert np.array_equal(eng.to_host(pl2.inverse(f)), a)
+        for st in (0, logn // 2, logn - 1):
+            got = eng.to_host(pl.forward_stages(eng.to_device(a, "cuda:0"), st))
+            assert np.array_equal(got, oracle.ntt(a, T, p, stage=st)), st
+        assert pl.count_noncanonical(eng.to_device(a, "cuda:0")) == 0
+        b = a.copy()
+        b[1, 7] = p
+        assert pl.count_noncanonical(eng.to_device(b, "cuda:0")) == 1
+    # negacyclic product (kind-2 table; separate passes with the pointwise leg folded into the first forward pass) and pointwise
+    for logn in (6, 12, 14):
+        n = 1 << logn
+        pl = eng.NTTPlan(logn, p, 8, 0)
+        T = pl.make_table(2, g)
+        assert np.array_equal(T, oracle.make_table(2, n, p, g))
+        pl.set_twiddles(T)
+        a, b = _rand(3, n, p, dt, 1), _rand(3, n, p, dt, 2)
+        pw = eng.to_host(pl.pointwise_mul(eng.to_device(a, "cuda:0"), eng.to_device(b, "cuda:0"), scale=12345))
+        assert np.array_equal(pw, oracle.pointwise(a, b, p, 12345))
+        c = eng.to_host(pl.polymul_negacyclic(eng.to_device(a, "cuda:0"), eng.to_device(b, "cuda:0")))
+        if logn <= 8:
+            want = np.stack([oracle.negacyclic_schoolbook(a[i], b[i], p) for i in range(3)]).astype(dt)
+        else:
+            A, B = oracle.intt(a, T, p), oracle.intt(b, T, p)
+            want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p)
+        assert np.array_equal(c, want), logn
+
+
+def test_general_64bit_modulus_any_odd(eng, oracle):
+    """Not only primes: a composite odd 64-bit modulus and an arbitrary table of units (the reference never checks primality);
+    2^64 - 59 (the largest 64-bit prime); a SMALL modulus in 8-byte words; even moduli are refused."""
+    dt = np.uint64
+    rng = np.random.default_rng(8)
+    for p in (0xFFFFFFFFFFFFFFC5, (1 << 61) - 1, 3 * 5 * 17 * 257 * 65537 * 641, 3329):
+        logn, n = 10, 1024
+        T = (rng.integers(0, 2**63, size=n, dtype=np.uint64) % np.uint64(p)).astype(dt)
+        T[T == 0] = 1
+        if p == 3 * 5 * 17 * 257 * 65537 * 641:  # keep every entry a unit of the composite modulus
+            T = np.array([int(t) if __import__("math").gcd(int(t), p) == 1 else 1 for t in T], dtype=dt)
+        pl = eng.NTTPlan(logn, p, 8, 0)
+        pl.set_twiddles(T)
+        a = _rand(4, n, p, dt, 3)
+        f = pl.forward(eng.to_device(a, "cuda:0"))
+        assert np.array_equal(eng.to_host(f), oracle.ntt(a, T, p)), p
+        assert np.array_equal(eng.to_host(pl.inverse(f)), a), p
+    with pytest.raises(eng.NTTError):
+        eng.NTTPlan(8, 1 << 62, 8, 0)

@@ -29,7 +29,7 @@ BIGINT = sorted(os.path.basename(f) for f in glob.glob(os.path.join(GOLDEN, "big
 
 
 def test_fixtures_present():
-    assert len(LITERAL) == 5 and len(BIGINT) == 6
+    assert len(LITERAL) == 5 and len(BIGINT) == 9
 
 
 @pytest.mark.parametrize("name", LITERAL)
