@@ -146,6 +146,13 @@ inline std::vector<PlanAlt> plan_alternatives(int n, int word_bytes, uint64_t p)
     // (4-byte N = 2^16 by modulus class, re-measured in round 3: 10 + 6 against 8 + 8 is -7.1 % for a lazy prime, -1.7 % for a
     // 31-bit one and +0.2 % -- noise -- for a 32-bit one; at batch 1 all within 1 %: one split, plan_passes()'s, for all classes)
     alts.push_back({def, 0});
+    if (n == 22 && word_bytes == 4 && !m32_lazy_modulus(p)) {
+        // N = 2^22 = 13 + 9 (two HBM trips, the 512-row column tile) against round 2's 8 + 7 + 7, same process, bursts of 20 launches
+        // (profiles/r03_n22_classes.txt): Goldilocks -1 .. -5 % at every batch, both directions; lazy 4-byte primes -3 .. -17 % forward,
+        // +4 .. +6 % inverse at batches 8 .. 32 and even from 64 on; the heavier 4-byte streams (p >= 2^30) gain only for one or two
+        // polynomials (-7 .. -14 %) and lose +5 .. +16 % from batch 8 on (their 13-stage pass is VALU-bound): three light passes there
+        alts.push_back({{{true, 0, 8}, {false, 8, 7}, {false, 15, 7}}, 3});
+    }
     if (word_bytes == 8 && n == 13) alts.push_back({{{true, 0, 13}}, NTT_ALT_MIN_BATCH_GL13});
     if (word_bytes == 4 && m32_lazy_modulus(p) && n == 14) alts.push_back({{{true, 0, 14}}, NTT_ALT_MIN_BATCH_M32_14});
     return alts;

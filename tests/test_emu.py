@@ -118,7 +118,9 @@ def test_plan_alternatives():
     assert g13[0][0] == [7, 6] and g13[1][0] == [13] and g13[1][1] >= 64      # one long pass only once the batch fills the device
     assert alts(14, 4, 998244353)[1][0] == [14] and len(alts(14, 4, 3221225473)) == 1  # the 14-stage pass pays for lazy primes only
     assert alts(16, 4, 998244353)[0][0] == [10, 6] == alts(16, 4, 3221225473)[0][0]  # measured equal for the 32-bit class: one split
-    assert alts(22, 8, GOLD)[0][0] == [13, 9] and alts(22, 4, 3329)[0][0] == [13, 9]
+    # N = 2^22: two trips (13 + 9) for Goldilocks and the lazy 4-byte primes; the heavier 4-byte streams take three light passes from batch 3 on
+    assert [x[0] for x in alts(22, 8, GOLD)] == [[13, 9]] == [x[0] for x in alts(22, 4, 3329)]
+    assert alts(22, 4, 3221225473) == [([13, 9], 0), ([8, 7, 7], 3)] == alts(22, 4, 2013265921)
 
 
 def test_field_arithmetic_edges():

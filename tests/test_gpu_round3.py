@@ -316,8 +316,8 @@ def test_general_64bit_modulus(eng, oracle, p, g):
         assert np.array_equal(eng.to_host(f), oracle.ntt(a, T, p, nthreads=4))
         assert np.array_equal(eng.to_host(pl2.inverse(f)), a)
         for st in (0, logn // 2, logn - 1):
-            got = eng.to_host(pl.forward_stages(eng.to_device(a, "cuda:0"), st))
-            assert np.array_equal(got, oracle.ntt(a, T, p, stage=st)), st
+            got = eng.to_host(pl.forward_stages(eng.to_device(a[:1], "cuda:0"), st))
+            assert np.array_equal(got, oracle.ntt(a[:1], T, p, stage=st)), st
         assert pl.count_noncanonical(eng.to_device(a, "cuda:0")) == 0
         b = a.copy()
         b[1, 7] = p

@@ -45,7 +45,10 @@ for v in args.variants:
     parts = rest.split("+")  # path[+ENV=VAL...]: set while this variant's plan is created (experiment builds read knobs there)
     path = parts[0] if os.path.isabs(parts[0]) else os.path.join(ROOT, parts[0])
     env = dict(q.split("=", 1) for q in parts[1:])
-    L = _lib.open_library(path)
+    try:
+        L = _lib.open_library(path)
+    except AttributeError:  # a build from before round 3 (no ntt_plan_select / _set_policy / _clone)
+        L = _lib.open_library(path, since_v3=False)
     h = C.c_void_p()
     old_env = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
