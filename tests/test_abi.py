@@ -66,10 +66,11 @@ def test_tools_and_bench_timed_region_do_not_touch_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import or run anything under oracle/:
     no script under tools/ mentions the oracle modules, and bench.py imports them only inside cpu_baseline()."""
     tools = os.path.join(ROOT, "tools")
-    for f in os.listdir(tools):
-        if f.endswith((".py", ".sh", ".hip")):
-            text = open(os.path.join(tools, f)).read()
-            assert "oracle_py" not in text and "libntt_oracle" not in text and "ntt_oracle" not in text, f
+    for dirpath, _, files in os.walk(tools):  # tools/ and tools/archive/
+        for f in files:
+            if f.endswith((".py", ".sh", ".hip")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle_py" not in text and "libntt_oracle" not in text and "ntt_oracle" not in text, f
     bench = open(os.path.join(ROOT, "bench.py")).read()
     assert bench.count("import oracle_py") == 1
     body = bench[bench.index("def cpu_baseline"):bench.index("def device_copy_rate")]

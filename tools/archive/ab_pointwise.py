@@ -2,7 +2,7 @@
 """Same-process A/B of ntt_pointwise_mul across library builds (one set of buffers for every variant, outputs compared):
 usage: ab_pointwise.py NAME=path ...   (1 GiB per operand, both word sizes, with and without the scale factor)"""
 import ctypes as C, os, statistics, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import bench_configs as B

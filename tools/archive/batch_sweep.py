@@ -2,7 +2,7 @@
 """Throughput against the batch at one size (looks for bad regimes between one generation of workgroups and saturation):
 forward, inverse, forward to AIE_BLOCK16, forward in place.  usage: batch_sweep.py word_bytes logn [max_log_batch]"""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import bench_configs as B

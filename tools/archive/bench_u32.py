@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """4-byte-word throughput at the BASELINE shapes (A/B with NTT_HIP_LIB=ab/libntt_NAME.so): forward / inverse ms."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import bench_configs as B
 B.run("cfg2: N=2^12, p=3221225473 (any), batch 1024", 12, 3221225473, 5, 4, 1024)

@@ -3,7 +3,7 @@
 load, compute and store phases of all 1024 workgroups in lockstep.  Sweep of the knobs that could overlap them
 (experiment build): fewer, longer workgroups (NTT_TARGET_WGS -> polynomials streamed per workgroup)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import _explib

@@ -2,7 +2,7 @@
 """Experiment for BASELINE config 2 (N = 2^12, 32-bit prime, batch 1024: one generation of workgroups in lockstep): the batch as
 K slices on K streams inside one hipGraph, so that the slices' load / compute / store phases are staggered by the launch gaps."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from ntt_aie_amd import NTTPlan

@@ -2,7 +2,7 @@
 """Experiment: per-pass time under NTT_DEBUG_FLAGS (1: loads hit L2, 2: no stores, 3: both = VALU floor).
 usage: dbg_sweep.py logn word_bytes [split]"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 # experiment knobs live only in libntt_hip_exp.so (make -C ntt_aie_amd/csrc exp): the product library reads no env
 sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -5,7 +5,7 @@ rocm-smi: dynamic power and energy per wave-instruction by instruction class.  S
 usage (GPU box): python3 tools/energy_probe.py [seconds per kernel]"""
 import os, re, subprocess, sys, threading, time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SEC = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
 exe = "/tmp/microbench2_power"
 subprocess.check_call(["hipcc", "-O2", "--offload-arch=gfx950", os.path.join(ROOT, "tools", "microbench2.hip"), "-o", exe])

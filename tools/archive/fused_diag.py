@@ -2,7 +2,7 @@
 step and the control words of the last launch (slots per XCC, status, completed column tiles, verdict).
 NTT_DEBUG_FLAGS=16/32/64 isolate the roles (see tools/fused_gl16.hip).  Usage: fused_diag.py BATCH"""
 import os, sys, time, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 # experiment knobs live only in libntt_hip_exp.so (make -C ntt_aie_amd/csrc exp): the product library reads no env
 sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -3,7 +3,7 @@
 the per-pass kernel times (measured: 1.797 / 1.775 / 1.757 ms per step: a graph recovers about 1 %)."""
 import os
 import sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ntt_aie_amd import NTTPlan
 GOLD = 0xFFFFFFFF00000001

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """40 inverse transforms of the headline batch (for rocprofv3 --kernel-trace --stats: per-kernel time of the inverse passes)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from bench import GOLDILOCKS, synth_batch

@@ -5,7 +5,7 @@ of the batch, so the same instruction stream runs with a footprint of G x 512 Ki
 G = 4096 is the real transform.  Prints per-pass hipEvent times, out of place and in place.
 usage: mall_probe.py [logn=16] [batch=4096]"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import _explib

@@ -2,7 +2,7 @@
 """Every transform mode (layouts, scaled / unscaled inverse, in place) against N at 1 GiB of coefficients: looks for a mode that falls off the
 curve of the plain forward transform."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import bench_configs as B

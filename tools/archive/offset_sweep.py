@@ -2,7 +2,7 @@
 """Experiment: does the relative placement of the input and output buffers matter (HBM channel / bank phase)?
 Per-pass time of the headline transform with the output buffer shifted by DELTA bytes inside one allocation."""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from ntt_aie_amd import NTTPlan

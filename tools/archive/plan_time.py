@@ -3,7 +3,7 @@
 its batch inversion and upload) against N, both word sizes."""
 import sys, time
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from ntt_aie_amd import NTTPlan
 GOLD = 0xFFFFFFFF00000001

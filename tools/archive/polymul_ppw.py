@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """polymul_ms against the workgroup-count target of the product kernel (experiment build).  usage: polymul_ppw.py logn batch"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import _explib

@@ -2,7 +2,7 @@
 """Negacyclic product and pointwise product at small sizes (or the sizes given: polymul_small.py logn ...), 1 GiB per operand: the sizes below the product kernel's range
 (Goldilocks N < 2^7, 4-byte words N < 2^5) fold only the pointwise leg into the forward pass.  One JSON line per shape."""
 import json, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import bench_configs as B

@@ -2,7 +2,7 @@
 """Polynomials streamed per workgroup (ppw) against the batch, for the first (CONTIG) and second (column) pass: per-pass time for
 NTT_TARGET_WGS / NTT_TARGET_WGS_COL targets that give ppw = 2 .. 32 (experiment build).  usage: ppw_sweep.py logn batch[,batch...]"""
 import os, statistics, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import _explib

@@ -4,7 +4,7 @@ product pass): the same launch repeated many times must give the same words ever
 occasional difference, long before it shows up in a parity test), and the first result is checked by the round trip.
 usage: race_soak.py [repeats=150]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import bench_configs as B

@@ -3,7 +3,7 @@
 (Goldilocks; NTT_SWEEP_WB=4 for 4-byte words).  usage: split_sweep.py logn split [split ...]
 e.g.  split_sweep.py 20 12,8 8,6,6 7,7,6"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 # experiment knobs live only in libntt_hip_exp.so (make -C ntt_aie_amd/csrc exp): the product library reads no env
 sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -2,7 +2,7 @@
 """Sweep of the workgroups-per-launch target (experiment build, NTT_TARGET_WGS / NTT_TARGET_WGS_COL) against the batch:
 per-pass kernel time (hipEvents, median of 15).  usage: wgs_sweep.py wb logn batch[,batch...]"""
 import os, statistics, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import _explib

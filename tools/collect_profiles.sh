@@ -1,12 +1,12 @@
 #!/bin/bash
 # Collect the judged profile set of one build on the GPU box (run through gpurun from the repo root):
-#   tools/collect_profiles.sh r02
+#   tools/collect_profiles.sh r03
 # kernel-trace stats of the bench command, HBM traffic (FETCH_SIZE / WRITE_SIZE in separate --pmc runs), SQ counters.
 # Everything lands under gpurun_out/prof_<tag>/ and the reduced summaries under gpurun_out/profiles_<tag>/ (copy the
 # latter into profiles/).  rocprofv3 gets `python3 bench.py ...` directly after `--` (no wrapper: the profiler's
 # preloaded library initialises the GPU before the program starts).
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
