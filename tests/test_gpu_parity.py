@@ -357,13 +357,20 @@ def test_bench_json_contract():
 
 @pytest.mark.parametrize("wb,p,g", [(8, GOLD, 7), (4, 3221225473, 5), (4, 998244353, 3)])
 def test_three_pass_sizes(eng, oracle, wb, p, g):
-    """N = 2^21 and 2^22: three HBM passes (CONTIG + two column passes), except that 2^21 = 13 + 8 stages takes two."""
+    """N = 2^21 = 13 + 8 and (round 3) 2^22 = 13 + 9 take two HBM passes; 2^23 three (CONTIG + two column passes).  For the heavy
+    4-byte streams the launcher switches N = 2^22 to 8 + 7 + 7 from batch 3 on (plan alternatives): batch 2 and batch 3 both run."""
     dt = np.uint32 if wb == 4 else np.uint64
-    for logn in (21, 22):
+    for logn in (21, 22, 23):
         n = 1 << logn
         T = oracle.make_roots(n, p, g, wb)
         pl = _plan(eng, logn, p, wb, T)
-        assert pl.hbm_passes == (2 if logn == 21 else 3)
+        assert pl.hbm_passes == (3 if logn == 23 else 2)
+        if logn == 22 and wb == 4 and p >= 2**30:
+            assert len(pl.passes_for(2)) == 2 and len(pl.passes_for(3)) == 3
+            a3 = _rand(3, n, p, dt, 5)
+            f3 = pl.forward(eng.to_device(a3, "cuda:0"))
+            assert np.array_equal(eng.to_host(f3), oracle.ntt(a3, T, p, nthreads=8))
+            assert np.array_equal(eng.to_host(pl.inverse(f3)), a3)
         a = _rand(2, n, p, dt, logn)
         f = pl.forward(eng.to_device(a, "cuda:0"))
         assert np.array_equal(eng.to_host(f), oracle.ntt(a, T, p, nthreads=8))
