@@ -75,6 +75,8 @@ hipError_t launch_gen_table_m64(void *T, int logn, int kind, uint64_t base_m, ui
 
 // out[i] = T[i] * c (table form both): the N/2 scaled stage-0 twiddles of the Goldilocks inverse transform
 hipError_t launch_scale_table_gl(const void *T, void *out, size_t count, uint64_t c_m, hipStream_t s);
+hipError_t launch_scale_table_m64(const void *T, void *out, size_t count, uint64_t c_m, uint64_t p, uint64_t pinv, uint64_t r2,
+                                  hipStream_t s);
 
 // number of words >= p in a buffer (precondition check); d_out = one zeroed 64-bit device word
 hipError_t launch_count_noncanonical(const void *a, size_t count, int word_bytes, uint64_t p, void *d_out, hipStream_t s);

@@ -218,6 +218,14 @@ hipError_t launch_scale_table_gl(const void *T, void *out, size_t count, uint64_
     return hipGetLastError();
 }
 
+hipError_t launch_scale_table_m64(const void *T, void *out, size_t count, uint64_t c_m, uint64_t p, uint64_t pinv, uint64_t r2,
+                                  hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(scale_table_kernel<FieldM64>, dim3(grid_for(count)), dim3(256), 0, s, (const uint64_t *) T,
+                       (uint64_t *) out, count, c_m, FieldM64{p, pinv, r2});
+    return hipGetLastError();
+}
+
 hipError_t launch_count_noncanonical(const void *a, size_t count, int word_bytes, uint64_t p, void *d_out, hipStream_t s) {
     if (word_bytes == 8)
         hipLaunchKernelGGL(count_noncanonical_kernel<uint64_t>, dim3(grid_for(count)), dim3(256), 0, s,

@@ -88,7 +88,7 @@ struct ntt_plan {
     // device tables, table form
     void *d_tw_fwd;
     void *d_tw_inv;
-    void *d_tw_inv_sc;  // 8-byte words: T^-1[N/2 + i] * N^-1, i < N/2 (stage-0 twiddles of the scaled inverse, pass.h: fold_scale)
+    void *d_tw_inv_sc;  // 8-byte words (both fields): T^-1[N/2 + i] * N^-1, i < N/2 (stage-0 twiddles of the scaled inverse, pass.h: fold_scale)
     bool has_table, has_inv;
     uint64_t scale_tf;     // N^-1 in table form
     uint64_t ninv_plain;   // N^-1 plain
@@ -122,7 +122,7 @@ hipError_t launch_inv(const ntt_plan *pl, const PassDesc &pd, const ntt::ErasedA
 }
 
 size_t table_bytes(const ntt_plan *pl) { return ((size_t) 1 << pl->logn) * pl->word_bytes; }
-size_t sc_table_bytes(const ntt_plan *pl) { return pl->fk == FK_GL ? table_bytes(pl) / 2 : 0; }
+size_t sc_table_bytes(const ntt_plan *pl) { return pl->word_bytes == 8 ? table_bytes(pl) / 2 : 0; }
 
 // the decomposition the launchers run for this batch
 const std::vector<PassDesc> &passes_for(const ntt_plan *pl, size_t batch) {
@@ -211,7 +211,7 @@ int run_inverse(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
         a.layout = layout;
         a.do_scale = (scale && i == 0) ? 1 : 0;
         a.scale = pl->scale_tf;
-        // Goldilocks: N^-1 rides on the last executed stage (stage 0 of the CONTIG pass) instead of a sweep over the outputs
+        // 8-byte words: N^-1 rides on the last executed stage (stage 0 of the CONTIG pass) instead of a sweep over the outputs
         a.tw_sc = a.do_scale ? pl->d_tw_inv_sc : nullptr;
         hipError_t e = launch_inv(pl, pd, a, s);
         if (e != hipSuccess) return (int) e;
@@ -448,6 +448,9 @@ int ntt_plan_generate_twiddles(ntt_plan_t pl, int kind, uint64_t g) {
         e = ntt::launch_gen_table_m64(pl->d_tw_fwd, pl->logn, kind, to_table_form(base, p, 8), one_m, p, pl->pinv64, pl->r2_64, nullptr);
         if (e == hipSuccess)
             e = ntt::launch_gen_table_m64(pl->d_tw_inv, pl->logn, kind, to_table_form(base_inv, p, 8), one_m, p, pl->pinv64, pl->r2_64, nullptr);
+        if (e == hipSuccess)
+            e = ntt::launch_scale_table_m64((const uint64_t *) pl->d_tw_inv + N / 2, pl->d_tw_inv_sc, N / 2, pl->scale_tf, p, pl->pinv64,
+                                            pl->r2_64, nullptr);
     } else if (wb == 8) {
         e = ntt::launch_gen_table_gl(pl->d_tw_fwd, pl->logn, kind, to_table_form(base, p, 8), one_m, nullptr);
         if (e == hipSuccess)

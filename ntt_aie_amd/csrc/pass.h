@@ -350,10 +350,11 @@ constexpr bool tw_uniform() {
 // N^-1 folded into the LAST executed stage of the scaled inverse transform (stage 0, in the CONTIG pass):
 //   (u, v) -> (u*c + v*(T^-1*c), u*c - v*(T^-1*c)),  c = N^-1
 // costs one extra product per butterfly of that stage (N/2 per transform) where a scaling sweep over the outputs costs N;
-// T^-1*c is a plan-time table of N/2 words (PassArgs::tw_sc).  Goldilocks only (the 4-byte streams keep phase_scale).
+// T^-1*c is a plan-time table of N/2 words (PassArgs::tw_sc).  8-byte words (Goldilocks and the general modulus); the 4-byte
+// streams keep phase_scale.
 template <class Cfg>
 constexpr bool fold_scale() {
-    return Cfg::INV && Cfg::CONTIG && std::is_same<typename Cfg::F, FieldGL>::value;
+    return Cfg::INV && Cfg::CONTIG && sizeof(typename Cfg::W) == 8;
 }
 
 // ---- host index model only: LDS hazard tracking -----------------------------------------
@@ -894,7 +895,7 @@ NTT_HD void phase_lds_write(Ctx<Cfg> &c, typename Cfg::W *lds, bool perm = false
 // SC: the N^-1 scaling is folded into stage 0 (fold_scale<Cfg>(); c.tw[0] then holds T^-1 * N^-1 for that stage)
 template <class Cfg, int r, int M32_MODE = -1, bool TW_READY = false, bool SC = false>
 NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
-    static_assert(!SC || fold_scale<Cfg>(), "folded scaling: Goldilocks inverse CONTIG passes only");
+    static_assert(!SC || fold_scale<Cfg>(), "folded scaling: inverse CONTIG passes of 8-byte words only");
     using W = typename Cfg::W;
     constexpr int b0 = Cfg::win(r);
     constexpr int lo = Cfg::stage_lo(r), hi = Cfg::stage_hi(r);
@@ -928,6 +929,34 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
                 } else {
                     if constexpr (!Cfg::INV) m32_fwd4_any(c.x[e0], c.x[e0 | S], T0, c.x[e1], c.x[e1 | S], T1, c.x[e2], c.x[e2 | S], T2, c.x[e3], c.x[e3 | S], T3, f.p, f.pinv);
                     else m32_inv4_any(c.x[e0], c.x[e0 | S], T0, c.x[e1], c.x[e1 | S], T1, c.x[e2], c.x[e2 | S], T2, c.x[e3], c.x[e3 | S], T3, f.p, f.pinv);
+                }
+            });
+            return;
+        }
+        if constexpr (std::is_same<typename Cfg::F, FieldM64>::value && Cfg::E >= 4) {
+            // general odd 64-bit modulus: the generated Montgomery streams (gl_asm.h: m64_*), two butterflies per statement;
+            // scratch at v[72:97] in the radix-8 kernels, v[102:127] in the radix-16 ones (as the Goldilocks streams)
+            static_for<0, Cfg::E / 4>([&](auto pp) {
+                constexpr int k0 = 2 * decltype(pp)::value, k1 = k0 + 1;
+                constexpr int eA = ((k0 >> t) << (t + 1)) | (k0 & ((1 << t) - 1));
+                constexpr int eB = ((k1 >> t) << (t + 1)) | (k1 & ((1 << t) - 1));
+                const W TA = c.tw[r][off + (eA >> (t + 1))], TB = c.tw[r][off + (eB >> (t + 1))];
+                if constexpr (SC && m == 0) {  // last executed stage with N^-1 folded in
+                    if constexpr (Cfg::LOG_E < 4) m64_invs2_v_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, a.scale, f.p, f.pinv);
+                    else m64_invs2_v(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, a.scale, f.p, f.pinv);
+                } else
+                if constexpr (tw_uniform<Cfg, r>() && Cfg::LOG_E < 4) {
+                    if constexpr (!Cfg::INV) m64_fwd2_s_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, f.p, f.pinv);
+                    else m64_inv2_s_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, f.p, f.pinv);
+                } else if constexpr (tw_uniform<Cfg, r>()) {
+                    if constexpr (!Cfg::INV) m64_fwd2_s(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, f.p, f.pinv);
+                    else m64_inv2_s(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, f.p, f.pinv);
+                } else if constexpr (Cfg::LOG_E < 4) {
+                    if constexpr (!Cfg::INV) m64_fwd2_v_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, f.p, f.pinv);
+                    else m64_inv2_v_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, f.p, f.pinv);
+                } else {
+                    if constexpr (!Cfg::INV) m64_fwd2_v(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, f.p, f.pinv);
+                    else m64_inv2_v(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, f.p, f.pinv);
                 }
             });
             return;
@@ -998,6 +1027,14 @@ NTT_HD void phase_scale(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
         static_for<0, Cfg::E / 2>([&](auto pp) {
             constexpr int e = 2 * decltype(pp)::value;
             gl_mul2_s(c.x[e], a.scale, c.x[e + 1], a.scale);
+        });
+        return;
+    }
+    if constexpr (std::is_same<typename Cfg::F, FieldM64>::value && Cfg::E >= 4) {
+        static_for<0, Cfg::E / 2>([&](auto pp) {
+            constexpr int e = 2 * decltype(pp)::value;
+            if constexpr (Cfg::LOG_E < 4) m64_mul2_s_lo(c.x[e], a.scale, c.x[e + 1], a.scale, a.field.p, a.field.pinv);
+            else m64_mul2_s(c.x[e], a.scale, c.x[e + 1], a.scale, a.field.p, a.field.pinv);
         });
         return;
     }

@@ -357,7 +357,7 @@ int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, con
         tw = t64.data();
     }
     std::vector<uint64_t> tsc;  // stage-0 twiddles of the scaled Goldilocks inverse, as ntt_plan_set_twiddles makes them
-    if (inverse && word_bytes == 8 && p == GOLDILOCKS) {
+    if (inverse && word_bytes == 8) {
         const uint64_t ninv = powmod(p / 2 + 1, (uint64_t) logn, p);
         tsc.resize(N / 2);
         for (size_t i = 0; i < N / 2; i++) tsc[i] = to_table_form(mulmod(Ti[N / 2 + i], ninv, p), p, 8);

@@ -122,3 +122,45 @@ def test_four_byte_word_streams(gen, mode, p):
                     assert gx < 2 * p and gy < 2 * p and gx % p == wx and gy % p == wy, (kind, mode, p, xv, yv, t)
                 else:
                     assert (gx, gy) == (wx, wy), (kind, mode, p, xv, yv, t)
+
+
+@pytest.mark.parametrize("p", [0x3FFFFFEE00000001, 0xFFFFFFFC00000001, P, 0xFFFFFFFFFFFFFFC5, (1 << 61) - 1, 3 * 5 * 17 * 257 * 65537 * 641,
+                               (1 << 63) + 29, 3329, 3])
+@pytest.mark.parametrize("vbase", [104, 72])
+def test_general_64bit_modulus_streams(gen, p, vbase):
+    """The FieldM64 streams (any odd p < 2^64, Montgomery R = 2^64) against Python integers: fwd64 / inv64 take canonical words,
+    the multiplied operand of mul64 may be ANY 64-bit word; edge residues around 0, p, 2^32, 2^63 and the carries they drive."""
+    rng = random.Random(p ^ vbase)
+    pinv = pow(p, -1, 1 << 64)
+    rinv = pow(1 << 64, -1, p)
+    edge = sorted({0, 1, 2 % p, p - 1, p - 2 if p > 2 else 0, p // 2, p // 2 + 1, ((1 << 32) - 1) % p, (1 << 32) % p, ((1 << 63) - 1) % p, (1 << 63) % p,
+                   0xFFFFFFFF00000000 % p})
+    tws = edge + [rng.randrange(p) for _ in range(4)]
+    for kind in ("fwd64", "inv64", "mul64", "invs64"):
+        lines = gen.stream(kind, 2, vbase)
+        pool = [(x, y) for x in edge for y in edge] + [(rng.randrange(p), rng.randrange(p)) for _ in range(200)]
+        if kind == "mul64":
+            pool += [(v, 0) for v in (p, (1 << 64) - 1, (1 << 63) + 5, p + 1 if p + 1 < (1 << 64) else p)]
+        for i, (x, y) in enumerate(pool):
+            vals = [{"x": x, "y": y, "t": tws[i % len(tws)]}, {"x": y if kind != "mul64" else x ^ 1, "y": x % p, "t": tws[(i + 5) % len(tws)]}]
+            if kind == "mul64":
+                vals = [{"x": v["x"], "t": v["t"]} for v in vals]
+            env = _env64(vbase, vals)
+            env.update({"%[p0]": p & 0xFFFFFFFF, "%[p1]": p >> 32, "%[pi0]": pinv & 0xFFFFFFFF, "%[pi1]": pinv >> 32,
+                        "%[vp0]": p & 0xFFFFFFFF, "%[vp1]": p >> 32})
+            cs = tws[(i + 2) % len(tws)]  # the folded scale constant of the invs64 stream
+            env["%[c0]"], env["%[c1]"] = cs & 0xFFFFFFFF, cs >> 32
+            env = gen.simulate(lines, env)
+            for b, v in enumerate(vals):
+                gx = _get(env, "x", b)
+                if kind == "invs64":
+                    u, w = v["x"] * cs * rinv % p, v["y"] * v["t"] * rinv % p
+                    assert gx == (u + w) % p and _get(env, "y", b) == (u - w) % p, (kind, p, v, cs)
+                    continue
+                if kind == "fwd64":
+                    assert gx == (v["x"] + v["y"]) % p and _get(env, "y", b) == (v["x"] - v["y"]) * v["t"] * rinv % p, (kind, p, v)
+                elif kind == "inv64":
+                    w = v["y"] * v["t"] * rinv % p
+                    assert gx == (v["x"] + w) % p and _get(env, "y", b) == (v["x"] - w) % p, (kind, p, v)
+                else:
+                    assert gx == v["x"] * v["t"] * rinv % p, (kind, p, v)

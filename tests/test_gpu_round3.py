@@ -179,24 +179,26 @@ print("OK")
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
-def test_scaled_inverse_fold_every_contig_shape(eng, oracle):
-    """N^-1 folded into stage 0 (pass.h: fold_scale): every Goldilocks CONTIG kernel shape as the LAST inverse pass -- radix-16
+@pytest.mark.parametrize("p,g", [(GOLD, 7), (0x3FFFFFEE00000001, 3)])
+def test_scaled_inverse_fold_every_contig_shape(eng, oracle, p, g):
+    """N^-1 folded into stage 0 (pass.h: fold_scale): every 8-byte CONTIG kernel shape as the LAST inverse pass -- radix-16
     single-pass sizes 2^1..2^12, radix-8 first passes of 7..12 stages (N = 2^13 .. 2^20), the 13-stage pass (2^21, 2^13 alt) --
-    with host-made tables (ntt_plan_set_twiddles) and device-made ones (ntt_plan_generate_twiddles); edge residues included."""
-    p, dt = GOLD, np.uint64
+    with host-made tables (ntt_plan_set_twiddles) and device-made ones (ntt_plan_generate_twiddles); edge residues included.
+    Goldilocks and the general 64-bit modulus (both fields fold)."""
+    dt = np.uint64
     for logn in list(range(1, 13)) + [13, 14, 15, 16, 17, 18, 19, 20, 21]:
         n = 1 << logn
         batch = 5 if logn <= 16 else 2
-        T = oracle.make_roots(n, p, 7, 8)
+        T = oracle.make_roots(n, p, g, 8)
         a = _rand(batch, n, p, dt, logn)
-        a[0, : min(n, 8)] = np.array([0, 1, p - 1, p - 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000, 2][: min(n, 8)], dtype=dt)
+        a[0, : min(n, 8)] = np.array([0, 1, p - 1, p - 2, 0xFFFFFFFF, 0x100000000, 0xFFFFFFFF00000000 % p, 2][: min(n, 8)], dtype=dt)
         f = oracle.ntt(a, T, p, nthreads=8)
         for made in ("host", "device"):
             pl = eng.NTTPlan(logn, p, 8, 0)
             if made == "host":
                 pl.set_twiddles(T)
             else:
-                pl.generate_twiddles(0, 7)
+                pl.generate_twiddles(0, g)
             for k in range(len(_alts(pl))):
                 pl.set_policy(k)
                 back = eng.to_host(pl.inverse(eng.to_device(f, "cuda:0")))

@@ -132,6 +132,97 @@ def butterfly(kind, b, vbase=104):
     return ins
 
 
+def butterfly64(kind, b, vbase=104):
+    """General odd 64-bit modulus (FieldM64, Montgomery R = 2^64): instruction list of butterfly `b`.  kind 'fwd64' | 'inv64' | 'mul64'.
+    23 VALU per product: 128-bit product (4 v_mad_u64_u32 + 3 glue), q = lo * p^-1 mod 2^64 (1 mad + 2 v_mul_lo + 1 add3),
+    hi64(q * p) (v_mul_hi + 3 mads + 2 glue; its low half equals the product's, so only the carry chain is computed),
+    r = hi - hi64(q*p), + p when negative (6).  Canonical modadd / modsub 6 each: 35 VALU per butterfly where hipcc's code for
+    the portable FieldM64 takes 42.6 + 4.8 s_nop.  Scalars: %[p0] %[p1] %[pi0] %[pi1] (SGPRs: one per instruction, the gfx9
+    constant-bus limit); the corrections that combine p with a carry held in an SGPR read p from two register-pinned VGPRs
+    %[vp0] %[vp1].  Fixed VGPR pairs as in butterfly(): L M A B H Z, A[1] pinned to zero."""
+    vb = vbase + 12 * b
+    L, M, A, B, H, Z = [(f"v{vb + 2 * i}", f"v{vb + 2 * i + 1}") for i in range(6)]
+    sb_ = 80 + 10 * b
+    sa, sbb, se, sf, s5 = [f"s[{sb_ + 2 * i}:{sb_ + 2 * i + 1}]" for i in range(5)]
+
+    def P(pair):
+        lo = int(pair[0][1:])
+        return f"v[{lo}:{lo + 1}]"
+
+    def o(name):
+        return f"%[{name}{b}]"
+
+    x0, x1, y0, y1, t0, t1 = o("x0_"), o("x1_"), o("y0_"), o("y1_"), o("t0_"), o("t1_")
+    d0, d1 = o("d0_"), o("d1_")
+    P0, P1, PI0, PI1, VP0, VP1 = "%[p0]", "%[p1]", "%[pi0]", "%[pi1]", "%[vp0]", "%[vp1]"
+    ins = []
+
+    def sub(a0, a1, b0, b1, out0, out1):
+        # (a - b) mod p, canonical operands: wrapped difference, + p when it borrowed.  6 VALU
+        ins.append(Ins(f"v_sub_co_u32 {Z[0]}, {se}, {a0}, {b0}", [a0, b0], [Z[0], se]))
+        ins.append(Ins(f"v_subb_co_u32 {Z[1]}, {se}, {a1}, {b1}, {se}", [a1, b1, se], [Z[1], se]))
+        ins.append(Ins(f"v_add_co_u32 {B[0]}, {sf}, {Z[0]}, {VP0}", [Z[0], VP0], [B[0], sf]))
+        ins.append(Ins(f"v_addc_co_u32 {B[1]}, {sf}, {Z[1]}, {VP1}, {sf}", [Z[1], VP1, sf], [B[1], sf]))
+        ins.append(Ins(f"v_cndmask_b32 {out0}, {Z[0]}, {B[0]}, {se}", [Z[0], B[0], se], [out0]))
+        ins.append(Ins(f"v_cndmask_b32 {out1}, {Z[1]}, {B[1]}, {se}", [Z[1], B[1], se], [out1]))
+
+    def add(a0, a1, b0, b1, out0, out1):
+        # (a + b) mod p, canonical operands: z = a + b (carry c), w = z - p (borrow g); out = (g & ~c) ? z : w.  6 VALU + 1 SALU
+        ins.append(Ins(f"v_add_co_u32 {Z[0]}, {se}, {a0}, {b0}", [a0, b0], [Z[0], se]))
+        ins.append(Ins(f"v_addc_co_u32 {Z[1]}, {se}, {a1}, {b1}, {se}", [a1, b1, se], [Z[1], se]))
+        ins.append(Ins(f"v_sub_co_u32 {B[0]}, {sf}, {Z[0]}, {VP0}", [Z[0], VP0], [B[0], sf]))
+        ins.append(Ins(f"v_subb_co_u32 {B[1]}, {sf}, {Z[1]}, {VP1}, {sf}", [Z[1], VP1, sf], [B[1], sf]))
+        ins.append(Ins(f"s_andn2_b64 {sf}, {sf}, {se}", [sf, se], [sf], salu=True))
+        ins.append(Ins(f"v_cndmask_b32 {out0}, {B[0]}, {Z[0]}, {sf}", [B[0], Z[0], sf], [out0]))
+        ins.append(Ins(f"v_cndmask_b32 {out1}, {B[1]}, {Z[1]}, {sf}", [B[1], Z[1], sf], [out1]))
+
+    def mul(m0, m1, r0, r1, t0=t0, t1=t1):
+        # (m1:m0) * (t1:t0) * 2^-64 mod p, canonical; m may be any 64-bit value, t < p
+        ins.append(Ins(f"v_mad_u64_u32 {P(L)}, {sbb}, {m0}, {t0}, 0", [m0, t0], [L[0], L[1], sbb]))
+        ins.append(Ins(f"v_mov_b32 {A[0]}, {L[1]}", [L[1]], [A[0]]))
+        ins.append(Ins(f"v_mad_u64_u32 {P(M)}, {sbb}, {m0}, {t1}, {P(A)}", [m0, t1, A[0], A[1]], [M[0], M[1], sbb]))
+        ins.append(Ins(f"v_mad_u64_u32 {P(M)}, {sa}, {m1}, {t0}, {P(M)}", [m1, t0, M[0], M[1]], [M[0], M[1], sa]))
+        ins.append(Ins(f"v_mov_b32 {B[0]}, {M[1]}", [M[1]], [B[0]]))
+        ins.append(Ins(f"v_cndmask_b32 {B[1]}, 0, 1, {sa}", [sa], [B[1]]))
+        ins.append(Ins(f"v_mad_u64_u32 {P(H)}, {sbb}, {m1}, {t1}, {P(B)}", [m1, t1, B[0], B[1]], [H[0], H[1], sbb]))   # H = P3:P2 ; lo = M0:L0
+        # q = lo * p^-1 mod 2^64
+        ins.append(Ins(f"v_mad_u64_u32 {P(Z)}, {sbb}, {L[0]}, {PI0}, 0", [L[0]], [Z[0], Z[1], sbb]))
+        ins.append(Ins(f"v_mul_lo_u32 {B[0]}, {L[0]}, {PI1}", [L[0]], [B[0]]))
+        ins.append(Ins(f"v_mul_lo_u32 {B[1]}, {M[0]}, {PI0}", [M[0]], [B[1]]))
+        ins.append(Ins(f"v_add3_u32 {Z[1]}, {Z[1]}, {B[0]}, {B[1]}", [Z[1], B[0], B[1]], [Z[1]]))                              # q = Z1:Z0
+        # hi64(q * p): (q*p) mod 2^64 == lo by construction, so only the carries into the high half are needed
+        ins.append(Ins(f"v_mul_hi_u32 {A[0]}, {Z[0]}, {P0}", [Z[0]], [A[0]]))                                                  # A = {hi32(q0 p0), 0}
+        ins.append(Ins(f"v_mad_u64_u32 {P(L)}, {sbb}, {Z[0]}, {P1}, {P(A)}", [Z[0], A[0], A[1]], [L[0], L[1], sbb]))
+        ins.append(Ins(f"v_mad_u64_u32 {P(L)}, {sa}, {Z[1]}, {P0}, {P(L)}", [Z[1], L[0], L[1]], [L[0], L[1], sa]))
+        ins.append(Ins(f"v_mov_b32 {B[0]}, {L[1]}", [L[1]], [B[0]]))
+        ins.append(Ins(f"v_cndmask_b32 {B[1]}, 0, 1, {sa}", [sa], [B[1]]))
+        ins.append(Ins(f"v_mad_u64_u32 {P(M)}, {sbb}, {Z[1]}, {P1}, {P(B)}", [Z[1], B[0], B[1]], [M[0], M[1], sbb]))           # M = hi64(q p)
+        # r = H - M, + p when it borrowed
+        ins.append(Ins(f"v_sub_co_u32 {H[0]}, {s5}, {H[0]}, {M[0]}", [H[0], M[0]], [H[0], s5]))
+        ins.append(Ins(f"v_subb_co_u32 {H[1]}, {s5}, {H[1]}, {M[1]}, {s5}", [H[1], M[1], s5], [H[1], s5]))
+        ins.append(Ins(f"v_add_co_u32 {Z[0]}, {sa}, {H[0]}, {VP0}", [H[0], VP0], [Z[0], sa]))
+        ins.append(Ins(f"v_addc_co_u32 {Z[1]}, {sa}, {H[1]}, {VP1}, {sa}", [H[1], VP1, sa], [Z[1], sa]))
+        ins.append(Ins(f"v_cndmask_b32 {r0}, {H[0]}, {Z[0]}, {s5}", [H[0], Z[0], s5], [r0]))
+        ins.append(Ins(f"v_cndmask_b32 {r1}, {H[1]}, {Z[1]}, {s5}", [H[1], Z[1], s5], [r1]))
+
+    if kind == "fwd64":    # x' = x + y ; y' = (x - y) * T
+        sub(x0, x1, y0, y1, d0, d1)
+        add(x0, x1, y0, y1, x0, x1)
+        mul(d0, d1, y0, y1)
+    elif kind == "inv64":  # w = y * T ; x' = x + w ; y' = x - w   (all canonical)
+        mul(y0, y1, d0, d1)
+        sub(x0, x1, d0, d1, y0, y1)
+        add(x0, x1, d0, d1, x0, x1)
+    elif kind == "mul64":  # x' = x * T
+        mul(x0, x1, x0, x1)
+    elif kind == "invs64":  # last inverse stage with N^-1 folded in (see butterfly(): "invs"): t = T^-1 * N^-1, c = N^-1 in SGPRs
+        mul(y0, y1, d0, d1)
+        mul(x0, x1, x0, x1, "%[c0]", "%[c1]")
+        sub(x0, x1, d0, d1, y0, y1)
+        add(x0, x1, d0, d1, x0, x1)
+    return ins
+
+
 def butterfly32(kind, b, mode, vbase=None):
     """4-byte-word Montgomery butterfly `b` (R = 2^32, twiddle in Montgomery form).
     mode "lazy":  p < 2^30, values kept in [0, 2p) (Harvey): no correction after the product, one
@@ -293,6 +384,8 @@ def simulate(lines, env):
             env[a[0]] = (rd(a[1]) * rd(a[2])) & M32
         elif op == "v_mul_hi_u32":
             env[a[0]] = (rd(a[1]) * rd(a[2])) >> 32
+        elif op == "v_add3_u32":
+            env[a[0]] = (rd(a[1]) + rd(a[2]) + rd(a[3])) & M32
         elif op == "v_add_u32":
             env[a[0]] = (rd(a[1]) + rd(a[2])) & M32
         elif op == "v_sub_u32":
@@ -310,6 +403,8 @@ def stream(kind, nb=2, vbase=104, mode=None):
     """The scheduled instruction lines of one statement (what emit()/emit32() put into gl_asm.h)."""
     if kind in ("fwd32", "inv32"):
         return schedule([butterfly32(kind, b, mode, vbase if vbase != 104 else M32_VBASE) for b in range(nb)])
+    if kind in ("fwd64", "inv64", "mul64", "invs64"):
+        return schedule([butterfly64(kind, b, vbase) for b in range(nb)])
     return schedule([butterfly(kind, b, vbase) for b in range(nb)])
 
 def emit32(kind, nb, mode, vbase=M32_VBASE):
@@ -456,6 +551,68 @@ def emit(kind, nb, tw_constraint, vbase=104, suffix=""):
     return "\n".join(src), len(lines), nops
 
 
+def emit64(kind, nb, tw_constraint, vbase=104, suffix="", vp=(102, 103)):
+    """One M64 statement.  vp: the two VGPRs pinned to p's halves (outside the 24 scratch registers of the two slots)."""
+    lists = [butterfly64(kind, b, vbase) for b in range(nb)]
+    lines = schedule(lists)
+    nops = sum(1 for l in lines if l.startswith("s_nop"))
+    name = f"m64_{kind[:-2]}{nb}_{'s' if tw_constraint == 's' else 'v'}{suffix}"
+    args = []
+    for b in range(nb):
+        if kind == "mul64":
+            args += [f"uint64_t &x{b}", f"uint64_t t{b}"]
+        else:
+            args += [f"uint64_t &x{b}", f"uint64_t &y{b}", f"uint64_t t{b}"]
+    if kind == "invs64":
+        args += ["uint64_t c"]
+    args += ["uint64_t p", "uint64_t pinv"]
+    valu = sum(1 for l in lines if l.startswith("v_"))
+    src = [f"// {kind} x{nb} (any odd p < 2^64): {len(lines)} instructions ({valu} VALU), {nops} s_nop",
+           f"__device__ __forceinline__ void {name}({', '.join(args)}) {{"]
+    for b in range(nb):
+        src.append(f"    uint32_t x0_{b} = (uint32_t) x{b}, x1_{b} = (uint32_t) (x{b} >> 32);")
+        if kind != "mul64":
+            src.append(f"    uint32_t y0_{b} = (uint32_t) y{b}, y1_{b} = (uint32_t) (y{b} >> 32);")
+        src.append(f"    const uint32_t t0_{b} = (uint32_t) t{b}, t1_{b} = (uint32_t) (t{b} >> 32);")
+        if kind != "mul64":
+            src.append(f"    uint32_t d0_{b}, d1_{b};")
+    src.append("    const uint32_t p0 = (uint32_t) p, p1 = (uint32_t) (p >> 32), pi0 = (uint32_t) pinv, pi1 = (uint32_t) (pinv >> 32);")
+    if kind == "invs64":
+        src.append("    const uint32_t c0 = (uint32_t) c, c1 = (uint32_t) (c >> 32);")
+    zero_regs = [vbase + 12 * b + 5 for b in range(nb)]
+    for b, r in enumerate(zero_regs):
+        src.append(f"    register uint32_t zero_{b} asm(\"v{r}\");  // high half of the 64-bit addend {{x, 0}} of v_mad_u64_u32")
+        src.append(f"    asm(\"v_mov_b32 %0, 0\" : \"=v\"(zero_{b}));")
+    # p in two pinned VGPRs, defined by side-effect-free asm: one pair of moves per kernel, not per statement
+    src.append(f"    register uint32_t vp0 asm(\"v{vp[0]}\"), vp1 asm(\"v{vp[1]}\");")
+    src.append("    asm(\"v_mov_b32 %0, %1\" : \"=v\"(vp0) : \"s\"(p0));")
+    src.append("    asm(\"v_mov_b32 %0, %1\" : \"=v\"(vp1) : \"s\"(p1));")
+    src.append("    asm volatile(")
+    for l in lines:
+        src.append(f'        "{l}\\n\\t"')
+    outs, ins_ = [], []
+    for b in range(nb):
+        outs += [f'[x0_{b}] "+v"(x0_{b})', f'[x1_{b}] "+v"(x1_{b})']
+        if kind != "mul64":
+            outs += [f'[y0_{b}] "+v"(y0_{b})', f'[y1_{b}] "+v"(y1_{b})']
+            outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("d0_", "d1_")]
+        ins_ += [f'[t0_{b}] "{tw_constraint}"(t0_{b})', f'[t1_{b}] "{tw_constraint}"(t1_{b})']
+    ins_ += ['[p0] "s"(p0)', '[p1] "s"(p1)', '[pi0] "s"(pi0)', '[pi1] "s"(pi1)', '[vp0] "v"(vp0)', '[vp1] "v"(vp1)']
+    if kind == "invs64":
+        ins_ += ['[c0] "s"(c0)', '[c1] "s"(c1)']
+    ins_ += [f'[zero_{b}] "v"(zero_{b})' for b in range(nb)]
+    clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 12 * nb) if r not in zero_regs] + [f'"s{r}"' for r in range(80, 80 + 10 * nb)]
+    src.append("        : " + ", ".join(outs))
+    src.append("        : " + ", ".join(ins_))
+    src.append("        : " + ", ".join(clob) + ");")
+    for b in range(nb):
+        src.append(f"    x{b} = ((uint64_t) x1_{b} << 32) | x0_{b};")
+        if kind != "mul64":
+            src.append(f"    y{b} = ((uint64_t) y1_{b} << 32) | y0_{b};")
+    src.append("}")
+    return "\n".join(src), len(lines), nops
+
+
 def main():
     out = ["// gl_asm.h -- GENERATED by tools/gen_gl_asm.py; do not edit.",
            "// Hand-scheduled gfx950 Goldilocks butterflies (two interleaved per statement); the",
@@ -490,6 +647,19 @@ def main():
             out.append(txt)
             out.append("")
             print(f"{kind} x4 {mode}: {n} instructions, {nops} nops", file=sys.stderr)
+    # general odd 64-bit modulus: heavy kernels (radix-16: scratch v[104:127], p in v[102:103]) and light ones (radix-8: v[72:95], v[96:97])
+    for kind in ("fwd64", "inv64", "mul64"):
+        for tw in ("v", "s"):
+            for vb, sfx, vp in ((104, "", (102, 103)), (72, "_lo", (96, 97))):
+                txt, n, nops = emit64(kind, 2, tw, vbase=vb, suffix=sfx, vp=vp)
+                out.append(txt)
+                out.append("")
+        print(f"{kind} x2: {n} instructions, {nops} nops", file=sys.stderr)
+    for vb, sfx, vp in ((104, "", (102, 103)), (72, "_lo", (96, 97))):  # scaled last inverse stage (stage-0 twiddles differ per thread: "v")
+        txt, n, nops = emit64("invs64", 2, "v", vbase=vb, suffix=sfx, vp=vp)
+        out.append(txt)
+        out.append("")
+    print(f"invs64 x2: {n} instructions, {nops} nops", file=sys.stderr)
     out += ["}  // namespace ntt", "#endif"]
     open(sys.argv[1] if len(sys.argv) > 1 else "ntt_aie_amd/csrc/gl_asm.h", "w").write("\n".join(out) + "\n")
 
