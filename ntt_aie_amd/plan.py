@@ -114,6 +114,17 @@ class NTTPlan:
         return [("contig" if i == 0 else "col", int(L.ntt_plan_info(self._h, 256 + 16 * alt + 8 + i)),
                  int(L.ntt_plan_info(self._h, 256 + 16 * alt + 1 + i))) for i in range(k)]
 
+    @property
+    def alternatives(self) -> list[tuple[list[int], int]]:
+        """[(stages per pass, smallest batch it is chosen for)] of every launch-time decomposition of this plan."""
+        L = _lib.lib()
+        out = []
+        for a in range(int(L.ntt_plan_info(self._h, 6))):
+            k = int(L.ntt_plan_info(self._h, 256 + 16 * a))
+            out.append(([int(L.ntt_plan_info(self._h, 256 + 16 * a + 1 + i)) for i in range(k)],
+                        int(L.ntt_plan_info(self._h, 256 + 16 * a + 15))))
+        return out
+
     def set_policy(self, alternative: int) -> None:
         """-1 (default): the launcher picks the decomposition by batch; k >= 0: always alternative k (ntt_plan_set_policy)."""
         check(_lib.lib().ntt_plan_set_policy(self._h, alternative), "ntt_plan_set_policy")

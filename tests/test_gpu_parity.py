@@ -571,15 +571,19 @@ def test_roctx_ranges_under_rocprofv3(tmp_path):
 
 
 def test_randomized_differential(eng, oracle):
-    """Seeded random sweep over moduli (tiny, around 2^31, up to 2^32-1, composite odd, Goldilocks), sizes, batches,
+    """Seeded random sweep over moduli (tiny, around 2^31, up to 2^32-1, composite odd, Goldilocks, general 64-bit), sizes, batches,
     layouts, in-place / out-of-place and both directions: every output word equals the oracle's.  The table rule is
     make_roots with its integer division (src/test.cpp:28), so the moduli need not be NTT-friendly."""
     moduli4 = [3, 5, 7, 3329, 12289, 40961, 65537, 786433, 8380417, 469762049, 998244353, 2013265921, 2147483647,
                2147483649, 2147483659, 3221225473, 4293918721, 4294967291, 4294967295]
+    # 8-byte words: Goldilocks (fast path) and general odd moduli (round 3: FieldM64) -- tiny, 33-bit, 62-bit, just below / above 2^63,
+    # the largest 64-bit prime, a composite, 2^64 - 1
+    moduli8 = [GOLD, GOLD, 3, 4294967311, 0x3FFFFFEE00000001, (1 << 63) - 25, (1 << 63) + 29, 0xFFFFFFFC00000001, 0xFFFFFFFFFFFFFFC5,
+               3 * 5 * 17 * 257 * 65537 * 641, (1 << 64) - 1]
     rng = np.random.default_rng(20261003)
-    for case in range(int(os.environ.get("NTT_TEST_RANDOM_CASES", "72"))):  # soak: NTT_TEST_RANDOM_CASES=2000
-        wb = 8 if case % 6 == 5 else 4
-        p = GOLD if wb == 8 else int(moduli4[int(rng.integers(len(moduli4)))])
+    for case in range(int(os.environ.get("NTT_TEST_RANDOM_CASES", "96"))):  # soak: NTT_TEST_RANDOM_CASES=2000
+        wb = 8 if case % 3 == 2 else 4
+        p = int(moduli8[int(rng.integers(len(moduli8)))]) if wb == 8 else int(moduli4[int(rng.integers(len(moduli4)))])
         g = int(rng.integers(2, 50))
         logn = int(rng.integers(1, 18 if case >= 72 else 16))
         n = 1 << logn
@@ -588,6 +592,9 @@ def test_randomized_differential(eng, oracle):
         dt = np.uint32 if wb == 4 else np.uint64
         T = oracle.make_roots(n, p, g, wb)
         pl = _plan(eng, logn, p, wb, T)
+        nalt = len(pl.alternatives)
+        if nalt > 1 and case % 2:  # pin a non-default decomposition now and then (plan alternatives compute the same words)
+            pl.set_policy(int(rng.integers(nalt)))
         a = _rand(batch, n, p, dt, case)
         want = oracle.ntt(a, T, p, nthreads=4)
         d = eng.to_device(a, "cuda:0")
