@@ -38,14 +38,8 @@
 #include "field.h"
 #include "gl_asm.h"
 
-#ifndef NTT_COL_PREFETCH
-#define NTT_COL_PREFETCH 0  // experiment knob: register prefetch in the 8-stage column pass
-#endif
 #ifndef NTT_SETPRIO
-#define NTT_SETPRIO 1  // bit 0: raise the wave priority (s_setprio 3) while it issues its global loads (column pass -1.3 %); bit 1: stores (no gain); bit 2: across an LDS exchange
-#endif
-#ifndef NTT_LATE_SYNC
-#define NTT_LATE_SYNC 0  // experiment knob: end-of-iteration barrier moved to before the next iteration's first LDS write (measured: column pass +2 %, worse)
+#define NTT_SETPRIO 1  // raise the wave priority (s_setprio 3) while a wave issues its global loads (column pass -1.3 %; around stores or LDS exchanges: no gain)
 #endif
 #ifndef NTT_PPW_CAP_CONTIG_INV
 #define NTT_PPW_CAP_CONTIG_INV 8  // cap on polynomials per workgroup, inverse radix-8 CONTIG passes (see PassCfg::PPW_CAP)
@@ -62,18 +56,8 @@
 #ifndef NTT_PPW_CAP_COL_INV
 #define NTT_PPW_CAP_COL_INV 4  // ... inverse Goldilocks column passes
 #endif
-#ifndef NTT_COL_DMA
-#define NTT_COL_DMA 0  // experiment knob: LDS-DMA prefetch in the 8-stage Goldilocks column pass, ONE tile buffer (the next
-                       // tile lands in it while the second round computes); measured in DESIGN.md section 8.5
-#endif
 #ifndef NTT_PRODUCT_TW_EARLY
 #define NTT_PRODUCT_TW_EARLY 1  // product pass: read the next round's LDS-table twiddles before the exchange barrier (measured -0.5 .. -0.9 %)
-#endif
-#ifndef NTT_PRODUCT_PREFETCH_A
-#define NTT_PRODUCT_PREFETCH_A 0  // product pass: also prefetch the NEXT unit's operand a during the forward rounds (b is always prefetched)
-#endif
-#ifndef NTT_INV_PREFETCH
-#define NTT_INV_PREFETCH 0  // experiment knob: register prefetch in the inverse CONTIG radix-8 passes (measured: no gain)
 #endif
 
 namespace ntt {
@@ -165,19 +149,7 @@ struct PassCfg {
     // ALLOW_DMA_ = false: the same radix-8 kernel with the tile staged by ordinary loads (phase_linear),
     // which is where a fused pointwise product has room to multiply.
     static constexpr bool DMA = ALLOW_DMA_ && CONTIG && !INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8;
-    // Column pass of 8 stages on 8-byte words (256 rows x one 128-byte segment, one unit per workgroup): the NEXT tile is
-    // fetched by LDS-DMA into the SAME buffer once the second round's words are in registers (experiment, NTT_COL_DMA).
-    // A wave-instruction lands 8 rows (1 KiB) linearly; 128 bytes of padding after every 16 rows keep the first round's
-    // reads (rows 16q + e of thread q) and the second round's (rows q + 16e) free of bank conflicts.
-    static constexpr bool CDMA = NTT_COL_DMA && ALLOW_DMA_ && !CONTIG && !INV && sizeof(W) == 8 && LOG_E_ == 4 && LOG_C_ == 4 &&
-                                 LOG_M_ == 8 && LOG_NT_ == 8;
-    // column passes of 8-byte words: the NEXT polynomial's 16 words per thread are loaded into a second
-    // register set while the current one is transformed (experiment knob NTT_COL_PREFETCH)
-    // ... and the inverse CONTIG radix-8 passes (direct loads of 8 words per thread, no DMA): NTT_INV_PREFETCH
-    static constexpr bool REG_PREFETCH = (NTT_COL_PREFETCH && !CONTIG && sizeof(W) == 8 && LOG_M_ == 8) ||
-                                         (NTT_INV_PREFETCH && CONTIG && INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8);
-
-    static constexpr int LDS_WORDS = CDMA ? TILE_WORDS + (TILE_WORDS >> 8) * 16 : LDS_WORDS_PADDED;
+    static constexpr int LDS_WORDS = LDS_WORDS_PADDED;
     // Most polynomials a workgroup streams through its resident twiddles (tools/ppw_sweep.py, N = 2^13 .. 2^17, batches
     // 2048 .. 16384): the 256-thread Goldilocks LDS-DMA first passes are fastest at 8 whatever the batch (16 costs 5-6 % at
     // batch 8192), the Goldilocks column passes at 4 (8 costs 4 %); the other kernels keep the workgroup-count rule alone.
@@ -185,7 +157,6 @@ struct PassCfg {
                                                               : (INV ? NTT_PPW_CAP_COL_INV : NTT_PPW_CAP_COL_FWD))
                                                    : 64;
     static NTT_HD uint32_t lds_index(uint32_t lin) {
-        if (CDMA) return lin + ((lin >> 8) << 4);  // 16 words after every 16 rows of 16 words
         return DMA ? lin : lin + ((lin >> LOG_E) * VW);
     }
 };
@@ -215,11 +186,9 @@ constexpr int contig_log_nt(int log_m, int word_bytes, bool last_pass) {
 // Column tile: 2^LOG_C consecutive words per row segment = one 128-byte line either way:
 // 16 columns of 8-byte words in 256-thread workgroups, 32 columns of 4-byte words in 512-thread ones
 // (with 16 columns the 4-byte passes moved 64-byte half lines: 3.9 ms against 1.8 ms per 4 GiB).
-#ifndef NTT_COL_GL_LOG_C
-#define NTT_COL_GL_LOG_C 4  // experiment knob: 5 = 256-byte row segments of 8-byte words in 512-thread workgroups
-#endif
-constexpr int col_log_c(int word_bytes) { return word_bytes == 8 ? NTT_COL_GL_LOG_C : 5; }
-constexpr int col_log_nt(int word_bytes) { return word_bytes == 8 ? 4 + NTT_COL_GL_LOG_C : 9; }
+// (256-byte segments of 8-byte words in 512-thread workgroups measured slower: profiles/NOTES_r02.md)
+constexpr int col_log_c(int word_bytes) { return word_bytes == 8 ? 4 : 5; }
+constexpr int col_log_nt(int word_bytes) { return word_bytes == 8 ? 8 : 9; }
 
 constexpr int contig_preload_mask(int log_m, int word_bytes, int log_e = 4) {
     if (log_e < 4) return 0xF;
@@ -231,14 +200,9 @@ constexpr int contig_preload_mask(int log_m, int word_bytes, int log_e = 4) {
     return log_m == 12 ? NTT_CONTIG12_MASK : 0x0;
 }
 
-#ifndef NTT_COL_E8
-#define NTT_COL_E8 0  // experiment knob: 8-stage Goldilocks column pass as radix-8 rounds in 512-thread workgroups
-#endif
+// radix-16 rounds; the 9-stage pass takes one more thread bit (a radix-8, 512-thread variant of the 8-stage pass measured slower)
 template <class F, int LOG_M, bool INV>
-using ColPassCfg = std::conditional_t<
-    NTT_COL_E8 && sizeof(typename F::W) == 8 && LOG_M == 8,
-    PassCfg<F, LOG_M, 4, false, INV, 0xF, 3, 9>,
-    PassCfg<F, LOG_M, col_log_c(sizeof(typename F::W)), false, INV, 0xF, 4, col_log_nt(sizeof(typename F::W)) + (LOG_M > 8 ? LOG_M - 8 : 0)>>;
+using ColPassCfg = PassCfg<F, LOG_M, col_log_c(sizeof(typename F::W)), false, INV, 0xF, 4, col_log_nt(sizeof(typename F::W)) + (LOG_M > 8 ? LOG_M - 8 : 0)>;
 
 // How the rows of blockIdx.y share the polynomial groups of the batch.  Rows [0, rows[0]) stream `ppw` groups each through
 // their resident twiddles; the next rows[1] rows ppw/2 each, then ppw/4, then ppw/8 (0 rows = level absent).  Rows are
@@ -282,7 +246,6 @@ template <class Cfg>
 struct Ctx {
     using W = typename Cfg::W;
     W x[Cfg::E];
-    W xn[Cfg::REG_PREFETCH ? Cfg::E : 1];  // prefetched words of the next iteration
     W tw[Cfg::R][Cfg::E > 1 ? Cfg::E - 1 : 1];
     uint32_t tid, bx, by;
     uint32_t pg_base;        // first polynomial group of this workgroup
@@ -305,7 +268,6 @@ struct Ctx {
 template <class Cfg>
 constexpr uint32_t lds_elem_off(int r, int e) {
     const uint32_t lin = (uint32_t) e << (Cfg::win(r) + Cfg::LOG_C);
-    if (Cfg::CDMA) return lin + ((lin >> 8) << 4);
     return Cfg::DMA ? lin : lin + ((lin >> Cfg::LOG_E) * Cfg::VW);
 }
 
@@ -545,7 +507,7 @@ __device__ __forceinline__ void buf_store(W v, __amdgpu_buffer_rsrc_t rs, uint32
 }
 #endif
 
-// loads the E words of round r's window of iteration `it` into dstx (c.x, the prefetch set c.xn, or a caller's array);
+// loads the E words of round r's window of iteration `it` into dstx (c.x or a caller's array);
 // `active`: whether this lane's polynomial of that iteration exists (ragged batch tail)
 template <class Cfg, int r>
 NTT_HD void phase_load_direct_to(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it, typename Cfg::W *dstx, bool active) {
@@ -581,9 +543,9 @@ NTT_HD void phase_load_direct_to(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it, ty
 #endif
 }
 
-template <class Cfg, int r, bool NEXT = false>
+template <class Cfg, int r>
 NTT_HD void phase_load_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
-    phase_load_direct_to<Cfg, r>(c, a, it, NEXT ? c.xn : c.x, c.active);
+    phase_load_direct_to<Cfg, r>(c, a, it, c.x, c.active);
 }
 
 template <class Cfg, int r>
@@ -596,7 +558,7 @@ NTT_HD void phase_store_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t voff = c.lane_st * (uint32_t) sizeof(W);
-    if constexpr (Cfg::DMA || Cfg::CDMA) {
+    if constexpr (Cfg::DMA) {
         // The LDS-DMA wait of the next iteration counts on EXACTLY E store instructions being
         // younger than the prefetch (phase_dma_wait): issue them by hand so that no compiler
         // decision (merging, splitting) can change that number.  Raw SRD: base, stride 0,
@@ -807,27 +769,6 @@ NTT_HD void phase_dma_issue(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W
 #endif
 }
 
-// Column tile (Cfg::CDMA): wave w fetches rows [64w, 64w + 64) of the 256-row tile, 8 rows (8 x 128 bytes) per instruction:
-// lane l copies the 16 bytes at row (l >> 3), piece (l & 7).  Device only (experiment knob).
-template <class Cfg>
-NTT_HD void phase_dma_issue_col(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *lds, int it) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    using W = typename Cfg::W;
-    const size_t tile0 = uniform_word<Cfg>(c, a, it);
-    const uint32_t wave = c.tid >> 6, lane = c.tid & 63u;
-    const uint32_t lds0 = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) W *) lds;
-    const W *g = a.in + tile0 + ((size_t) (wave * 64u + (lane >> 3)) << a.s0) + (lane & 7u) * 2u;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t chunk = wave * 8u + (uint32_t) i;  // 8 rows = 1 KiB each; 128 bytes of padding after every 2 chunks
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds0 + chunk * 1024u + (chunk >> 1) * 128u);
-        glds16(g + ((size_t) (8 * i) << a.s0), dst);
-    }
-#else
-    (void) c; (void) a; (void) lds; (void) it;
-#endif
-}
-
 // wait until this wave's DMA of the current tile has landed.  VMEM operations retire in order:
 // the only younger ones are the E stores of the previous iteration, which may stay in flight.
 template <class Cfg, bool FIRST_ITER>
@@ -972,15 +913,7 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
                     if constexpr (Cfg::LOG_E < 4) gl_invs2_v_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, a.scale);
                     else gl_invs2_v(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB, a.scale);
                 } else
-                if constexpr (!Cfg::CONTIG && Cfg::LOG_E < 4) {  // experimental light column kernel: scratch at v[56:79]
-                    if constexpr (tw_uniform<Cfg, r>()) {
-                        if constexpr (!Cfg::INV) gl_fwd2_s_lo2(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
-                        else gl_inv2_s_lo2(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
-                    } else {
-                        if constexpr (!Cfg::INV) gl_fwd2_v_lo2(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
-                        else gl_inv2_v_lo2(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
-                    }
-                } else if constexpr (tw_uniform<Cfg, r>() && Cfg::LOG_E < 4) {
+                if constexpr (tw_uniform<Cfg, r>() && Cfg::LOG_E < 4) {
                     if constexpr (!Cfg::INV) gl_fwd2_s_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
                     else gl_inv2_s_lo(c.x[eA], c.x[eA | (1 << t)], TA, c.x[eB], c.x[eB | (1 << t)], TB);
                 } else if constexpr (tw_uniform<Cfg, r>()) {
@@ -1070,17 +1003,15 @@ NTT_HD void phase_canon(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
     }
 }
 
-// raise the wave priority around a phase / drop it again; compiled in only for the phases NTT_SETPRIO selects
-template <int BIT>
+// raise the wave priority while a wave issues its global loads, so that the requests get out ahead of the other waves' VALU work
 NTT_HD void prio_up() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr ((NTT_SETPRIO & BIT) != 0) __builtin_amdgcn_s_setprio(3);
+    if constexpr (NTT_SETPRIO != 0) __builtin_amdgcn_s_setprio(3);
 #endif
 }
-template <int BIT>
 NTT_HD void prio_down() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr ((NTT_SETPRIO & BIT) != 0) __builtin_amdgcn_s_setprio(0);
+    if constexpr (NTT_SETPRIO != 0) __builtin_amdgcn_s_setprio(0);
 #endif
 }
 
@@ -1095,18 +1026,13 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     constexpr int FIRST = Cfg::INV ? R - 1 : 0;
     constexpr int LAST = Cfg::INV ? 0 : R - 1;
     constexpr bool ANY_LDS = R > 1 || !Cfg::DIRECT_LOAD || !Cfg::DIRECT_STORE;
-    // The barrier that keeps the next iteration from rewriting the tile while a slower wave still reads it is
-    // only needed before that iteration's FIRST LDS WRITE.  When the iteration starts with direct global loads
-    // and a register round, it is placed there (after the round) instead of at the end of the iteration: a wave
-    // issues its next loads right behind its stores and computes a round while the others catch up.
-    constexpr bool LATE_SYNC = NTT_LATE_SYNC && Cfg::DIRECT_LOAD && R > 1 && !Cfg::DMA && !Cfg::REG_PREFETCH;
     // Tile staged linearly through LDS by ordinary loads (forward CONTIG passes without LDS-DMA: every 4-byte-word one, the
     // Goldilocks radix-16 ones): the first tile's loads are issued BEFORE the resident twiddles are fetched, so that in a
     // one-generation launch (BASELINE config 2: 1024 workgroups, all resident at once) the coefficient requests are the oldest
     // in flight and the table reads overlap their latency instead of preceding it.  (The same reordering for the kernels
     // that load straight into the round registers measured neutral to +3 % on 4-byte words and costs the 8-byte column
     // pass 2 VGPRs beyond 128: not done.)  Exec::early_ok = false (tools-side fused schedule) keeps the old order.
-    constexpr bool EARLY_LOAD = Exec::early_ok && !Cfg::DIRECT_LOAD && !Cfg::DMA && !Cfg::REG_PREFETCH && !Cfg::CDMA;
+    constexpr bool EARLY_LOAD = Exec::early_ok && !Cfg::DIRECT_LOAD && !Cfg::DMA;
     if constexpr (EARLY_LOAD) ex.init_indices(a);
     else ex.init(a);
     auto group_valid = [&](int it) {  // uniform: does polynomial group `it` of this workgroup exist
@@ -1119,41 +1045,6 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
     if constexpr (Cfg::DMA) {
         if (group_valid(0)) ex.each([&](C &c) { phase_dma_issue<Cfg>(c, a, ex.lds(), 0); });
     }
-    if constexpr (Cfg::REG_PREFETCH) {
-        if (group_valid(0)) ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, 0); phase_load_direct<Cfg, FIRST, true>(c, a, 0); });
-    }
-    if constexpr (Cfg::CDMA) {
-        // One tile buffer: [wait for this wave's pieces] barrier [read round 0] compute [write] barrier [read round 1]
-        // barrier [issue the NEXT tile's DMA into the same buffer] compute round 1, store.
-        static_assert(R == 2 && Cfg::LOG_U == 0 && !Cfg::INV, "8-stage forward column pass");
-        if (group_valid(0)) ex.each([&](C &c) { phase_dma_issue_col<Cfg>(c, a, ex.lds(), 0); });
-        for (int it = 0; it < ex.ppw(); ++it) {
-            if (!group_valid(it)) break;
-            ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, it); });
-            typename Cfg::W *const tile = ex.lds();
-#if defined(NTT_EXPERIMENT)
-            const bool no_stores = (a.dbg & 2) != 0;  // timing experiment: nothing younger than the DMA to leave in flight
-#else
-            const bool no_stores = false;
-#endif
-            if (it == 0 || no_stores) ex.each([&](C &) { phase_dma_wait<Cfg, true>(); });
-            else ex.each([&](C &) { phase_dma_wait<Cfg, false>(); });
-            ex.sync(std::false_type{});  // every wave's rows have landed
-            ex.each([&](C &c) { phase_lds_read<Cfg, 0>(c, tile); });
-            ex.each([&](C &c) { phase_compute<Cfg, 0, M32_MODE>(c, a); });
-            ex.each([&](C &c) { phase_lds_write<Cfg, 0>(c, tile); });
-            ex.sync(std::false_type{});
-            ex.each([&](C &c) { phase_lds_read<Cfg, 1>(c, tile); });
-            ex.sync(std::false_type{});  // the tile is dead: the next one may land in it
-            prio_up<1>();
-            if (group_valid(it + 1)) ex.each([&](C &c) { phase_dma_issue_col<Cfg>(c, a, ex.lds(), it + 1); });
-            prio_down<1>();
-            ex.each([&](C &c) { phase_compute<Cfg, 1, M32_MODE>(c, a); });
-            ex.each([&](C &c) { phase_canon<Cfg>(c, a); });
-            ex.each([&](C &c) { phase_store_direct<Cfg, 1>(c, a, it); });
-        }
-        return;
-    }
     int completed = 0;
     for (int it = 0; it < ex.ppw(); ++it) {
         if (!group_valid(it)) break;
@@ -1163,20 +1054,14 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         if constexpr (Cfg::DMA) {
             if (it == 0) ex.each([&](C &) { phase_dma_wait<Cfg, true>(); });
             else ex.each([&](C &) { phase_dma_wait<Cfg, false>(); });
-            prio_up<1>();
+            prio_up();
             if (group_valid(it + 1)) ex.each([&](C &c) { phase_dma_issue<Cfg>(c, a, ex.lds(), it + 1); });
-            prio_down<1>();
+            prio_down();
             ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, tile); });
-        } else if constexpr (Cfg::REG_PREFETCH) {
-            ex.each([&](C &c) {
-#pragma unroll
-                for (int e = 0; e < Cfg::E; ++e) c.x[e] = c.xn[e];
-            });
-            if (group_valid(it + 1)) ex.each([&](C &c) { phase_load_direct<Cfg, FIRST, true>(c, a, it + 1); });
         } else if constexpr (Cfg::DIRECT_LOAD) {
-            prio_up<1>();
+            prio_up();
             ex.each([&](C &c) { phase_load_direct<Cfg, FIRST>(c, a, it); });
-            prio_down<1>();
+            prio_down();
         } else {
             if (!EARLY_LOAD || it > 0) ex.each([&](C &c) { phase_linear_issue<Cfg>(c, a, it); });
             ex.each([&](C &c) { phase_linear_commit<Cfg>(c, a, tile, it); });
@@ -1191,14 +1076,9 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.each([&](C &c) { phase_compute<Cfg, r, M32_MODE, false, SC>(c, a); });
             if constexpr (k < R - 1) {
                 constexpr int rn = Cfg::INV ? r - 1 : r + 1;
-                if constexpr (LATE_SYNC && k == 0) {
-                    if (it > 0) ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});  // previous iteration's tile reads are done
-                }
-                prio_up<4>();
                 ex.each([&](C &c) { phase_lds_write<Cfg, r>(c, tile); });
                 ex.sync(std::integral_constant<bool, Cfg::exchange_wave_local(r, rn)>{});
                 ex.each([&](C &c) { phase_lds_read<Cfg, rn>(c, tile); });
-                prio_down<4>();
             }
         });
         // (a configuration that CAN fold the scaling never runs the sweep: its launcher picks SC whenever do_scale is set, so
@@ -1206,9 +1086,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         if constexpr (Cfg::INV && !SC && !fold_scale<Cfg>()) ex.each([&](C &c) { phase_scale<Cfg>(c, a); });
         ex.each([&](C &c) { phase_canon<Cfg>(c, a); });
         if constexpr (Cfg::DIRECT_STORE) {
-            prio_up<2>();
             ex.each([&](C &c) { phase_store_direct<Cfg, LAST>(c, a, it); });
-            prio_down<2>();
         } else {
             ex.each([&](C &c) { phase_lds_write<Cfg, LAST>(c, tile, !Cfg::INV && block16_here<Cfg>(a)); });
             ex.sync(std::integral_constant<bool, LAST == 0 || Cfg::WAVE_LOCAL>{});  // round 0's words of a wave's threads are that wave's segment of the linear copy
@@ -1216,7 +1094,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         }
         ex.iter_done(it);  // fused schedule: publish the previous polynomial's tile
         ++completed;
-        if constexpr (ANY_LDS && !LATE_SYNC) {
+        if constexpr (ANY_LDS) {
             ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});  // next iteration rewrites the tile
         }
     }
@@ -1287,9 +1165,6 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
     auto group_valid = [&](int it) {
         return it < ex.ppw() && (((uint64_t) ex.pg_base() + (uint64_t) it) << aa.log_up) < aa.batch;
     };
-    auto lane_active = [&](const Ctx<CI> &c, int it) {  // does this lane's polynomial of iteration `it` exist
-        return CI::LOG_U == 0 ? true : ((((c.pg_base + (uint32_t) it) << aa.log_up) | c.up) < aa.batch);
-    };
     auto inverse_unit = [&](const PassArgs<CI> &a, W *tile) {  // on the words already in ci.x
         static_for<0, R>([&](auto kk) {
             constexpr int r = R - 1 - decltype(kk)::value;
@@ -1305,30 +1180,19 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
             }
         });
     };
-    // Register prefetch: operand b is fetched while operand a is transformed, and the next unit's operand a while this
-    // unit's product is transformed forward; the three data sets (working words, kept transform of a, prefetch) are
-    // never live together, 2 x E words at any time.
-    if (NTT_PRODUCT_PREFETCH_A && group_valid(0)) {
-        prio_up<1>();
-        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *, W *pre) { phase_load_direct_to<CI, R - 1>(ci, aa, 0, pre, lane_active(ci, 0)); });
-        prio_down<1>();
-    }
+    // Register prefetch: operand b is fetched while operand a is transformed (prefetching the next unit's a as well spilled
+    // registers and lost: profiles/NOTES_r02.md); working words + kept transform of a or prefetch: 2 x E words live at any time.
     for (int it = 0; it < ex.ppw(); ++it) {
         if (!group_valid(it)) break;
         W *const tile = ex.lds();
-        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &cf, W *, W *pre) {
+        ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &cf, W *, W *) {
             phase_begin_iter<CI>(ci, aa, it);
             cf.active = ci.active;
-            if (NTT_PRODUCT_PREFETCH_A) {
-#pragma unroll
-                for (int e = 0; e < CI::E; ++e) ci.x[e] = pre[e];
-            } else {
-                phase_load_direct_to<CI, R - 1>(ci, aa, it, ci.x, ci.active);
-            }
+            phase_load_direct_to<CI, R - 1>(ci, aa, it, ci.x, ci.active);
         });
-        prio_up<1>();
+        prio_up();
         ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *, W *pre) { phase_load_direct_to<CI, R - 1>(ci, ab, it, pre, ci.active); });
-        prio_down<1>();
+        prio_down();
         inverse_unit(aa, tile);
         ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *keep, W *pre) {
 #pragma unroll
@@ -1358,11 +1222,6 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
 #pragma unroll
             for (int e = 0; e < CI::E; ++e) cf.x[e] = af.field.mul(af.field.mul(keep[e], ci.x[e]), af.pw_scale);
         });
-        if (NTT_PRODUCT_PREFETCH_A && group_valid(it + 1)) {
-            prio_up<1>();
-            ex.eachIF([&](Ctx<CI> &ci, Ctx<CF> &, W *, W *pre) { phase_load_direct_to<CI, R - 1>(ci, aa, it + 1, pre, lane_active(ci, it + 1)); });
-            prio_down<1>();
-        }
         // no barrier here: the forward rounds first WRITE the round-0 positions, which this thread itself read last
         static_for<0, R>([&](auto kk) {
             constexpr int r = decltype(kk)::value;

@@ -49,11 +49,11 @@ def _cases(rng, pool_x, pool_y, n_random):
         yield rng.getrandbits(64), rng.getrandbits(64)
 
 
-@pytest.mark.parametrize("vbase", [104, 72, 56])
+@pytest.mark.parametrize("vbase", [104, 72])
 def test_goldilocks_streams(gen, vbase):
     rng = random.Random(vbase)
     tw = EDGE + [rng.randrange(P) for _ in range(6)]
-    for kind in ("fwd", "inv", "mul") + (("invs",) if vbase != 56 else ()):
+    for kind in ("fwd", "inv", "mul", "invs"):
         lines = gen.stream(kind, 2, vbase)
         canon_in = kind == "fwd"  # forward butterflies take canonical words; the others any 64-bit representative of x
         pool_x = EDGE if canon_in else ANY

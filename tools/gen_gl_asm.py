@@ -637,10 +637,9 @@ def main():
             print(f"invs x2: {n} instructions, {nops} nops", file=sys.stderr)
         if kind != "mul":
             for tw in ("v", "s"):  # for the radix-8 (light) kernels: scratch lives lower
-                for vb, sfx in ((72, "_lo"), (56, "_lo2")):
-                    txt, n, nops = emit(kind, 2, tw, vbase=vb, suffix=sfx)
-                    out.append(txt)
-                    out.append("")
+                txt, n, nops = emit(kind, 2, tw, vbase=72, suffix="_lo")
+                out.append(txt)
+                out.append("")
     for kind in ("fwd32", "inv32"):
         for mode in ("lazy", "small", "any"):
             txt, n, nops = emit32(kind, 4, mode)
