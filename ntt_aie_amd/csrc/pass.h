@@ -952,10 +952,22 @@ NTT_HD void phase_compute(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
     });
 }
 
-template <class Cfg>
+template <class Cfg, int M32_MODE = -1>
 NTT_HD void phase_scale(Ctx<Cfg> &c, const PassArgs<Cfg> &a) {
     if (!a.do_scale) return;
 #if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (std::is_same<typename Cfg::F, FieldM32>::value && Cfg::E >= 8 && M32_MODE >= 0) {
+        // four products by the wave-uniform N^-1 per statement; canonical results in every modulus class (5 / 5 / 6 instructions
+        // per word where hipcc's code for the portable product takes 8)
+        static_for<0, Cfg::E / 4>([&](auto pp) {
+            constexpr int e = 4 * decltype(pp)::value;
+            const uint32_t sc = (uint32_t) a.scale;
+            if constexpr (M32_MODE == 0) m32_mul4_lazy(c.x[e], c.x[e + 1], c.x[e + 2], c.x[e + 3], sc, a.field.p, a.field.pinv);
+            else if constexpr (M32_MODE == 1) m32_mul4_small(c.x[e], c.x[e + 1], c.x[e + 2], c.x[e + 3], sc, a.field.p, a.field.pinv);
+            else m32_mul4_any(c.x[e], c.x[e + 1], c.x[e + 2], c.x[e + 3], sc, a.field.p, a.field.pinv);
+        });
+        return;
+    }
     if constexpr (std::is_same<typename Cfg::F, FieldGL>::value && Cfg::E >= 2) {
         static_for<0, Cfg::E / 2>([&](auto pp) {
             constexpr int e = 2 * decltype(pp)::value;
@@ -1083,7 +1095,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         });
         // (a configuration that CAN fold the scaling never runs the sweep: its launcher picks SC whenever do_scale is set, so
         // the unscaled kernel carries neither the sweep's code nor its 24 scratch registers)
-        if constexpr (Cfg::INV && !SC && !fold_scale<Cfg>()) ex.each([&](C &c) { phase_scale<Cfg>(c, a); });
+        if constexpr (Cfg::INV && !SC && !fold_scale<Cfg>()) ex.each([&](C &c) { phase_scale<Cfg, M32_MODE>(c, a); });
         ex.each([&](C &c) { phase_canon<Cfg>(c, a); });
         if constexpr (Cfg::DIRECT_STORE) {
             ex.each([&](C &c) { phase_store_direct<Cfg, LAST>(c, a, it); });

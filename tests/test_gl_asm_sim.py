@@ -99,6 +99,15 @@ def test_four_byte_word_streams(gen, mode, p):
     top = 2 * p if mode == "lazy" else p  # lazy streams keep values in [0, 2p)
     edge = sorted({0, 1, p - 1, p // 2, top - 1, top - 2 if top > 2 else 0, p % top, (p + 1) % top})
     tws = sorted({0, 1, p - 1, p // 2 + 1}) + [rng.randrange(p) for _ in range(4)]
+    lines = gen.stream("mul32", 4, mode=mode)  # the scaling sweep: any 32-bit input word (lazy values included), canonical output
+    for i, x in enumerate(edge + [top - 1, (1 << 32) - 1 if mode != "lazy" else 2 * p - 1] + [rng.randrange(top) for _ in range(200)]):
+        env = {"%[p]": p, "%[npinv]": (-pinv) & 0xFFFFFFFF}
+        ts = [tws[(i + b) % len(tws)] for b in range(4)]
+        for b in range(4):
+            env["%%[x_%d]" % b], env["%%[t_%d]" % b] = (x + b) % (1 << 32) if mode != "lazy" else (x + b) % top, ts[b]
+        want = [env["%%[x_%d]" % b] * ts[b] * rinv % p for b in range(4)]
+        gen.simulate(lines, env)
+        assert [env["%%[x_%d]" % b] for b in range(4)] == want, (mode, p, x)
     for kind in ("fwd32", "inv32"):
         lines = gen.stream(kind, 4, mode=mode)
         cases = [(x, y) for x in edge for y in edge] + [(rng.randrange(top), rng.randrange(top)) for _ in range(300)]

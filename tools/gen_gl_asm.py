@@ -293,6 +293,14 @@ def butterfly32(kind, b, mode, vbase=None):
         ins.append(Ins(f"v_mul_lo_u32 {t1}, {L[0]}, {NPI}", [L[0]], [t1]))
         ins.append(Ins(f"v_mad_u64_u32 {LP}, vcc, {t1}, {P}, {LP}", [t1, L[0], L[1]], [L[0], L[1], "vcc"]))
 
+    if kind == "mul32":  # x' = x * T, canonical whatever the mode (the N^-1 sweep of the scaled inverse: T = N^-1, wave-uniform)
+        if mode == "lazy":
+            lazy_mul(x, ta)                                                     # [0, 2p)
+            ins.append(Ins(f"v_subrev_u32 {tb}, {P}, {L[1]}", [L[1]], [tb]))    # wraps (huge) when < p
+            ins.append(Ins(f"v_min_u32 {x}, {L[1]}, {tb}", [L[1], tb], [x]))
+        else:
+            mul(x, x, ta, tb)
+        return ins
     if mode == "lazy":
         if kind == "fwd32":    # x' = x + y ; y' = (x - y + 2p) * T
             ins.append(Ins(f"v_sub_u32 {tc}, {x}, {y}", [x, y], [tc]))
@@ -401,7 +409,7 @@ def simulate(lines, env):
 
 def stream(kind, nb=2, vbase=104, mode=None):
     """The scheduled instruction lines of one statement (what emit()/emit32() put into gl_asm.h)."""
-    if kind in ("fwd32", "inv32"):
+    if kind in ("fwd32", "inv32", "mul32"):
         return schedule([butterfly32(kind, b, mode, vbase if vbase != 104 else M32_VBASE) for b in range(nb)])
     if kind in ("fwd64", "inv64", "mul64", "invs64"):
         return schedule([butterfly64(kind, b, vbase) for b in range(nb)])
@@ -413,22 +421,29 @@ def emit32(kind, nb, mode, vbase=M32_VBASE):
     nops = sum(1 for l in lines if l.startswith("s_nop"))
     name = f"m32_{kind[:3]}{nb}_{mode}"
     what = {"lazy": "p < 2^30, values in [0, 2p)", "small": "p < 2^31", "any": "any odd p < 2^32"}[mode]
-    args = ", ".join(f"uint32_t &x{b}, uint32_t &y{b}, uint32_t t{b}" for b in range(nb))
-    extra = ", uint32_t p2" if mode == "lazy" else ""
+    if kind == "mul32":
+        args = ", ".join(f"uint32_t &x{b}" for b in range(nb)) + ", uint32_t t"
+    else:
+        args = ", ".join(f"uint32_t &x{b}, uint32_t &y{b}, uint32_t t{b}" for b in range(nb))
+    extra = ", uint32_t p2" if mode == "lazy" and kind != "mul32" else ""
     src = [f"// {kind} x{nb} ({what}): {len(lines)} instructions, {nops} s_nop",
            f"__device__ __forceinline__ void {name}({args}, uint32_t p, uint32_t pinv{extra}) {{"]
     for b in range(nb):
-        src.append(f"    uint32_t a_{b}, b_{b}, c_{b};")
+        src.append(f"    uint32_t a_{b}, b_{b}, c_{b};" if kind != "mul32" else f"    uint32_t a_{b}, b_{b};")
     src.append("    asm volatile(")
     for l in lines:
         src.append(f'        "{l}\\n\\t"')
     outs, ins_ = [], []
     for b in range(nb):
-        outs += [f'[x_{b}] "+v"(x{b})', f'[y_{b}] "+v"(y{b})']
-        outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("a_", "b_", "c_")]
-        ins_ += [f'[t_{b}] "v"(t{b})']
+        if kind == "mul32":
+            outs += [f'[x_{b}] "+v"(x{b})'] + [f'[{r}{b}] "=&v"({r}{b})' for r in ("a_", "b_")]
+            ins_ += [f'[t_{b}] "s"(t)']  # the one wave-uniform multiplier
+        else:
+            outs += [f'[x_{b}] "+v"(x{b})', f'[y_{b}] "+v"(y{b})']
+            outs += [f'[{r}{b}] "=&v"({r}{b})' for r in ("a_", "b_", "c_")]
+            ins_ += [f'[t_{b}] "v"(t{b})']
     ins_ += ['[p] "s"(p)', '[npinv] "s"(0u - pinv)']
-    if mode == "lazy":
+    if mode == "lazy" and kind != "mul32":
         ins_ += ['[p2] "s"(p2)']
     clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 2 * nb)]
     if mode == "any":
@@ -640,7 +655,7 @@ def main():
                 txt, n, nops = emit(kind, 2, tw, vbase=72, suffix="_lo")
                 out.append(txt)
                 out.append("")
-    for kind in ("fwd32", "inv32"):
+    for kind in ("fwd32", "inv32", "mul32"):
         for mode in ("lazy", "small", "any"):
             txt, n, nops = emit32(kind, 4, mode)
             out.append(txt)
