@@ -15,7 +15,7 @@ GOLD = 0xFFFFFFFF00000001
 def rand(batch, n, wb, p, seed):
     g = torch.Generator(device="cuda:0").manual_seed(seed)
     if wb == 8:
-        hi = torch.randint(0, 0xFFFFFFFF, (batch, n), dtype=torch.int64, device="cuda:0", generator=g)
+        hi = torch.randint(0, min(0xFFFFFFFF, max(1, p >> 32)), (batch, n), dtype=torch.int64, device="cuda:0", generator=g)  # canonical: < p
         lo = torch.randint(0, 1 << 32, (batch, n), dtype=torch.int64, device="cuda:0", generator=g)
         return (hi << 32) | lo
     return torch.randint(0, p, (batch, n), dtype=torch.int64, device="cuda:0", generator=g).to(torch.int32)

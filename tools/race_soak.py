@@ -4,7 +4,7 @@ product pass): the same launch repeated many times must give the same words ever
 occasional difference, long before it shows up in a parity test), and the first result is checked by the round trip.
 usage: race_soak.py [repeats=150]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import bench_configs as B
@@ -12,7 +12,11 @@ from ntt_aie_amd import NTTPlan
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 shapes = [(4, 3221225473, 5, 12, 4099), (4, 998244353, 3, 13, 2053), (4, 3221225473, 5, 21, 5), (8, B.GOLD, 7, 12, 2053), (8, B.GOLD, 7, 20, 37),
-          (8, B.GOLD, 7, 21, 9), (8, B.GOLD, 7, 18, 131), (4, 998244353, 3, 20, 67), (8, B.GOLD, 7, 16, 1031), (4, 12289, 11, 8, 100003)]
+          (8, B.GOLD, 7, 21, 9), (8, B.GOLD, 7, 18, 131), (4, 998244353, 3, 20, 67), (8, B.GOLD, 7, 16, 1031), (4, 12289, 11, 8, 100003),
+          # round 3: the 13-stage alternative of 8-byte N = 2^13 and the 14-stage one of lazy 4-byte N = 2^14 (batches above their thresholds),
+          # the 9-stage column pass (N = 2^22, three fields), the general 64-bit modulus (generated streams, folded scaling)
+          (8, B.GOLD, 7, 13, 1031), (4, 998244353, 3, 14, 1031), (8, B.GOLD, 7, 22, 5), (4, 998244353, 3, 22, 9), (4, 3221225473, 5, 22, 2),
+          (8, 0x3FFFFFEE00000001, 3, 16, 517), (8, 0xFFFFFFFC00000001, 10, 12, 2053), (8, 0x3FFFFFEE00000001, 3, 21, 5)]
 bad = 0
 for wb, p, g, logn, batch in shapes:
     n = 1 << logn
@@ -30,7 +34,7 @@ for wb, p, g, logn, batch in shapes:
         diff += int(not torch.equal(plan.inverse(x, y), i0))
         if r % 5 == 0:
             diff += int(not torch.equal(plan.polymul_negacyclic(x.clone(), b.clone()), c0))
-    print("wb=%d logn=%d batch=%d passes=%s: %d differing results in %d repeats" % (wb, logn, batch, plan.passes, diff, reps), flush=True)
+    print("wb=%d p=%d logn=%d batch=%d passes=%s: %d differing results in %d repeats" % (wb, p, logn, batch, plan.passes_for(batch), diff, reps), flush=True)
     bad += diff
     del x, b, y, f0, i0, c0
 sys.exit(1 if bad else 0)
