@@ -45,6 +45,9 @@ bool have_gl_product_mid(int log_m);   // Goldilocks: unit sizes 2^7 .. 2^12
 // one grid covers the batch (blockIdx.y range) -- computed by the launcher's own geometry call
 bool gl_product_mid_fits(int log_m, int n, uint32_t batch, uint32_t target_wgs);
 bool m32_product_mid_fits(int log_m, int n, uint32_t batch, uint32_t target_wgs);
+hipError_t launch_m64_product_mid(int log_m, const ErasedArgs &a, hipStream_t s);
+bool have_m64_product_mid(int log_m);  // general 64-bit modulus: unit sizes 2^7 .. 2^12, as Goldilocks
+bool m64_product_mid_fits(int log_m, int n, uint32_t batch, uint32_t target_wgs);
 hipError_t launch_m32_product_mid(int log_m, const ErasedArgs &a, hipStream_t s);
 bool have_m32_product_mid(int log_m);  // 4-byte words: unit sizes 2^6 .. 2^13
 

@@ -683,14 +683,15 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
     // Goldilocks, first (or only) pass of 7..12 stages: the radix-8 product kernel exists for that unit size.  A single-pass
     // size (2^7 <= N <= 2^12) is then ONE launch for the whole product: read a, read b, write c.
     // ... 4-byte words: radix-16 product kernel, unit sizes 2^6 .. 2^13 (any odd p: all three butterfly streams).
-    // (the general 64-bit modulus has no product kernel: separate passes, pointwise product folded into the first forward pass)
-    bool fused_mid = first.contig && pl->fk != FK_M64 && (pl->fk == FK_GL ? ntt::have_gl_product_mid(first.log_m)
-                                                                          : ntt::have_m32_product_mid(first.log_m));
+    bool fused_mid = first.contig && (pl->fk == FK_GL    ? ntt::have_gl_product_mid(first.log_m)
+                                      : pl->fk == FK_M64 ? ntt::have_m64_product_mid(first.log_m)
+                                                         : ntt::have_m32_product_mid(first.log_m));
     if (fused_mid) {
         // the product launch is not sliced: beyond blockIdx.y's range (tens of millions of tiny polynomials) take the
         // separate passes, whose launcher slices the batch.  The check IS the launcher's geometry call (product_fits).
-        fused_mid = pl->fk == FK_GL ? ntt::gl_product_mid_fits(first.log_m, pl->logn, (uint32_t) batch, pl->target_wgs)
-                                        : ntt::m32_product_mid_fits(first.log_m, pl->logn, (uint32_t) batch, pl->target_wgs);
+        fused_mid = pl->fk == FK_GL    ? ntt::gl_product_mid_fits(first.log_m, pl->logn, (uint32_t) batch, pl->target_wgs)
+                    : pl->fk == FK_M64 ? ntt::m64_product_mid_fits(first.log_m, pl->logn, (uint32_t) batch, pl->target_wgs)
+                                       : ntt::m32_product_mid_fits(first.log_m, pl->logn, (uint32_t) batch, pl->target_wgs);
     }
     if (fused_mid) {
         // The column passes (if any) of both unscaled inverse transforms, then ONE launch that runs
@@ -717,8 +718,9 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
             a.tw2 = pl->d_tw_fwd;
             a.layout = NTT_LAYOUT_NATURAL;
             a.pw_scale = to_table_form(to_table_form(pl->ninv_plain % pl->p, pl->p, pl->word_bytes), pl->p, pl->word_bytes);
-            hipError_t e = pl->fk == FK_GL ? ntt::launch_gl_product_mid(first.log_m, a, s)
-                                               : ntt::launch_m32_product_mid(first.log_m, a, s);
+            hipError_t e = pl->fk == FK_GL    ? ntt::launch_gl_product_mid(first.log_m, a, s)
+                           : pl->fk == FK_M64 ? ntt::launch_m64_product_mid(first.log_m, a, s)
+                                              : ntt::launch_m32_product_mid(first.log_m, a, s);
             if (e != hipSuccess) return (int) e;
         }
         for (size_t i = 1; i < passes.size(); i++) {

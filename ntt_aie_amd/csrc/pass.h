@@ -1230,6 +1230,17 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
                 });
                 return;
             }
+            if constexpr (std::is_same<typename CI::F, FieldM64>::value && CI::E >= 2 && CI::LOG_E < 4) {
+                // (both factors canonical here: the general modulus keeps canonical sums; the multiplier of m64_mul2 must be < p)
+                static_for<0, CI::E / 2>([&](auto pp) {
+                    constexpr int e = 2 * decltype(pp)::value;
+                    m64_mul2_v_lo(keep[e], ci.x[e], keep[e + 1], ci.x[e + 1], af.field.p, af.field.pinv);
+                    m64_mul2_s_lo(keep[e], af.pw_scale, keep[e + 1], af.pw_scale, af.field.p, af.field.pinv);
+                    cf.x[e] = keep[e];
+                    cf.x[e + 1] = keep[e + 1];
+                });
+                return;
+            }
 #endif
 #pragma unroll
             for (int e = 0; e < CI::E; ++e) cf.x[e] = af.field.mul(af.field.mul(keep[e], ci.x[e]), af.pw_scale);
@@ -1260,13 +1271,13 @@ NTT_HD void run_product_pass(Exec &ex, const PassArgs<CI> &aa, const PassArgs<CI
 #ifndef NTT_PRODUCT_MASK
 #define NTT_PRODUCT_MASK(R, UNIFORM_TOP) ((UNIFORM_TOP) ? ((1 << ((R) -1)) | 1) : 1)
 #endif
-template <int LOG_M>
+template <int LOG_M, class F = FieldGL>  // F: FieldGL, or FieldM64 (the general 64-bit modulus runs the same radix-8 schedule)
 struct ProductCfg {
     static constexpr int LOG_NT = LOG_M >= 10 ? 9 : 8;
     static constexpr int R = (LOG_M + 2) / 3;
     static constexpr bool UNIFORM_TOP = LOG_NT + 3 - LOG_M == 0;  // one unit per workgroup
-    using CI = PassCfg<FieldGL, LOG_M, 0, true, true, NTT_PRODUCT_MASK(R, UNIFORM_TOP), 3, LOG_NT, false>;
-    using CF = PassCfg<FieldGL, LOG_M, 0, true, false, NTT_PRODUCT_MASK(R, UNIFORM_TOP), 3, LOG_NT, false>;
+    using CI = PassCfg<F, LOG_M, 0, true, true, NTT_PRODUCT_MASK(R, UNIFORM_TOP), 3, LOG_NT, false>;
+    using CF = PassCfg<F, LOG_M, 0, true, false, NTT_PRODUCT_MASK(R, UNIFORM_TOP), 3, LOG_NT, false>;
 };
 
 // 4-byte words: radix-16 rounds in 256-thread workgroups (the shape of every 4-byte CONTIG pass; 512 threads for the 13-stage unit), unit sizes 2^5 .. 2^13

@@ -488,6 +488,12 @@ int emu_polymul_fused(int word_bytes, int logn, uint64_t p, const void *T_plain,
         e.pinv = mont_pinv((uint32_t) p);
         e.r2 = mont_r2((uint32_t) p);
     }
+    const bool m64 = word_bytes == 8 && p != GOLDILOCKS;
+    e.p64 = p;
+    if (m64) {
+        e.pinv64 = mont_pinv64(p);
+        e.r2_64 = mont_r2_64(p);
+    }
     e.n = logn;
     e.batch = batch;
     e.target_wgs = target_wgs;
@@ -497,14 +503,22 @@ int emu_polymul_fused(int word_bytes, int logn, uint64_t p, const void *T_plain,
             e.out = buf;
             e.tw = ti;
             e.s0 = passes[i].s0;
-            const int rc = word_bytes == 8 ? dispatch<FieldGL, true>(passes[i].contig, passes[i].log_m, e)
-                                           : dispatch<FieldM32, true>(passes[i].contig, passes[i].log_m, e);
+            const int rc = m64 ? dispatch<FieldM64, true>(passes[i].contig, passes[i].log_m, e)
+                           : word_bytes == 8 ? dispatch<FieldGL, true>(passes[i].contig, passes[i].log_m, e)
+                                             : dispatch<FieldM32, true>(passes[i].contig, passes[i].log_m, e);
             if (rc) return rc;
         }
-    const uint64_t ninv = powmod((p + 1) / 2, (uint64_t) logn, p);
+    const uint64_t ninv = powmod(p / 2 + 1, (uint64_t) logn, p);
     const uint64_t pw = to_table_form(to_table_form(ninv, p, word_bytes), p, word_bytes);
     int rc = -1;
-    if (word_bytes == 8) {
+    if (m64) {
+        switch (m0) {
+#define PM(M) case M: rc = run_product_mid<ProductCfg<M, FieldM64>>(logn, batch, target_wgs, a, b, out, ti, tf, pw, e); break;
+            PM(7) PM(8) PM(9) PM(10) PM(11) PM(12)
+#undef PM
+            default: return -1;
+        }
+    } else if (word_bytes == 8) {
         switch (m0) {
 #define PM(M) case M: rc = run_product_mid<ProductCfg<M>>(logn, batch, target_wgs, a, b, out, ti, tf, pw, e); break;
             PM(7) PM(8) PM(9) PM(10) PM(11) PM(12)
@@ -525,8 +539,9 @@ int emu_polymul_fused(int word_bytes, int logn, uint64_t p, const void *T_plain,
         e.out = out;
         e.tw = tf;
         e.s0 = passes[i].s0;
-        rc = word_bytes == 8 ? dispatch<FieldGL, false>(passes[i].contig, passes[i].log_m, e)
-                             : dispatch<FieldM32, false>(passes[i].contig, passes[i].log_m, e);
+        rc = m64 ? dispatch<FieldM64, false>(passes[i].contig, passes[i].log_m, e)
+             : word_bytes == 8 ? dispatch<FieldGL, false>(passes[i].contig, passes[i].log_m, e)
+                               : dispatch<FieldM32, false>(passes[i].contig, passes[i].log_m, e);
         if (rc) return rc;
     }
     return 0;

@@ -165,7 +165,8 @@ def test_fused_pointwise_first_pass(oracle):
 
 @pytest.mark.parametrize("wb,p,g,logn", [(8, GOLD, 7, l) for l in (7, 9, 10, 12, 13, 14, 16, 17, 18, 19, 20)] +
                          [(4, 998244353, 3, l) for l in (5, 6, 8, 10, 11, 12, 13, 14, 16, 17, 19, 21)] +
-                         [(4, 2013265921, 31, 9), (4, 3221225473, 5, 7), (4, 3221225473, 5, 12), (4, 3221225473, 5, 14)])
+                         [(4, 2013265921, 31, 9), (4, 3221225473, 5, 7), (4, 3221225473, 5, 12), (4, 3221225473, 5, 14)] +
+                         [(8, 0x3FFFFFEE00000001, 3, l) for l in (7, 10, 12, 14, 18)] + [(8, 0xFFFFFFFC00000001, 10, 9)])  # general 64-bit modulus
 def test_product_fused_middle_pass(oracle, wb, p, g, logn):
     """The negacyclic product the way the device runs it when the first pass has a product kernel (pass.h: run_product_pass:
     last inverse pass of both operands + pointwise + first forward pass per workgroup-resident unit -- the whole product for

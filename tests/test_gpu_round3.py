@@ -322,8 +322,8 @@ def test_general_64bit_modulus(eng, oracle, p, g):
         b = a.copy()
         b[1, 7] = p
         assert pl.count_noncanonical(eng.to_device(b, "cuda:0")) == 1
-    # negacyclic product (kind-2 table; separate passes with the pointwise leg folded into the first forward pass) and pointwise
-    for logn in (6, 12, 14):
+    # negacyclic product (kind-2 table; the fused middle pass instantiated for FieldM64, as for Goldilocks) and pointwise
+    for logn in (6, 12, 14, 17, 20):  # 2^6: pointwise folded into the forward pass; 2^12: ONE fused launch; 2^14 / 2^17 / 2^20: fused middle of 8 / 9 / 12 stages
         n = 1 << logn
         pl = eng.NTTPlan(logn, p, 8, 0)
         T = pl.make_table(2, g)
@@ -336,8 +336,8 @@ def test_general_64bit_modulus(eng, oracle, p, g):
         if logn <= 8:
             want = np.stack([oracle.negacyclic_schoolbook(a[i], b[i], p) for i in range(3)]).astype(dt)
         else:
-            A, B = oracle.intt(a, T, p), oracle.intt(b, T, p)
-            want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p)
+            A, B = oracle.intt(a, T, p, nthreads=8), oracle.intt(b, T, p, nthreads=8)
+            want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T, p, nthreads=8)
         assert np.array_equal(c, want), logn
 
 
