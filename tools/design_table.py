@@ -32,7 +32,7 @@ tbl = """| quantity (`profiles/r03_bench.json`, `r03_kernel_stats.csv`, `r03_pmc
 | what holds the clock | the 1400 W board cap: transform %.0f W at %.2f GHz; arithmetic alone %.0f W at %.2f GHz; copy alone %.0f W (`profiles/r03_power_probe.txt`) |
 | VALU floor (same kernels, loads from L2, no stores; measured in the bench run) | %.3f + %.3f ms (cycle view: `r03_sq_real_vs_floor.txt`) |
 | CPU baseline (oracle port, same run) | %.0f NTT/s on 1 thread; %.2f k on the %d cores the box's cgroup quota allows (affinity mask %d) |
-| inverse (config 3's second leg) | %.2f ms, %.3f × forward in this run (1.02–1.04 across collections), round trip identical |
+| inverse (config 3's second leg) | %.2f ms, %.3f × forward (0.999–1.006 over four runs; 1.03–1.04 before the inverse leg got the forward leg's untimed lead-in), round trip identical |
 
 """ % (d["value"] / 1e6, d["butterflies_per_s"] / 1e12, d["ms_per_step"], spread, r["pass_ms"][0], k0, r["pass_ms"][1], k1, r["achieved"] / 1e3, r["frac"],
        r["traffic"] / 1e9, r["pass_stream_GBs"][0] / 1e3, r["pass_stream_GBs"][1] / 1e3, min(r["pass_stream_frac"]), max(r["pass_stream_frac"]),
