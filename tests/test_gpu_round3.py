@@ -360,3 +360,25 @@ def test_general_64bit_modulus_any_odd(eng, oracle):
         assert np.array_equal(eng.to_host(pl.inverse(f)), a), p
     with pytest.raises(eng.NTTError):
         eng.NTTPlan(8, 1 << 62, 8, 0)
+
+
+def test_bench_quotes_only_matching_forward_counters():
+    """The headline bench line quotes hardware counters from profiles/r03_*.json only when their kernel-source hash equals the
+    tree's, and then only the FORWARD kernels' entries (INV argument false); otherwise it says why not."""
+    from ntt_aie_amd import _lib
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
+                          "--no-valu-floor", "--no-inverse"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    r = d["roofline"]
+    assert d["config"]["baseline_config"] == 3 and "inverse" not in d
+    stamped = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["src_hash"]
+    if stamped == _lib.kernel_source_hash():
+        assert r["traffic"] is not None and 1.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 2.1  # two trips, no over-fetch
+        assert "forward kernels" in r["traffic_source"] and ", true," not in r["traffic_source"].split("forward kernels:")[1].replace("true, false", "")
+        v = r["valu"]
+        assert v is not None and all(20 < x < 26 for x in v["instr_per_butterfly"]) and 0 < v["frac_at_held_clock"] <= 1
+        assert all("false" in k.split(",")[4] for k in v["kernels"])  # PassCfg<F, LOG_M, LOG_C, CONTIG, INV, ...>: INV == false
+    else:
+        assert r["traffic"] is None and r["valu"] is None and "not quoted" in r["traffic_source"]
