@@ -16,7 +16,14 @@
  *   - every entry point returns int: 0 = ok, negative = NTT_E_* argument/state
  *     error, positive = hipError_t from the runtime.  Nothing throws or aborts
  *     (reference error contract: ERT state != COMPLETED -> message + return 1,
- *     src/test.cpp:162-166).
+ *     src/test.cpp:162-166): every entry point is a function-try-block
+ *     (csrc/guard.h), a failed host allocation comes back as NTT_E_NOMEM.
+ *   - ALIGNMENT: every device DATA pointer handed to a transform (d_in, d_out,
+ *     d_a, d_b, d_buf) must be 16-byte aligned -- the kernels move 128-bit
+ *     vectors.  hipMalloc / torch allocations are (256 bytes); a row view
+ *     &buf[b*N] is whenever N * word_bytes is a multiple of 16, i.e. always
+ *     except N = 2 with 4-byte words (and N = 1 rows do not exist: logn >= 1).
+ *     A misaligned pointer is refused with NTT_E_ARG before any launch.
  *   - device buffers are caller-owned; polynomials are contiguous [batch][N]
  *     words in the reference's element order (natural order in, src/test.cpp:141).
  *     Words are uint32_t (any odd p < 2^32) or uint64_t (any odd p < 2^64; p = 2^64 - 2^32 + 1 takes a faster path).
@@ -52,7 +59,9 @@ enum {
     NTT_E_NOTINVERTIBLE = -5, /* inverse requested but a twiddle is not a unit mod p (0, or shares a factor with a composite p) */
     NTT_E_LAYOUT = -6,     /* NTT_LAYOUT_AIE_BLOCK16 needs N >= 16 */
     NTT_E_RANGE = -7,      /* a twiddle handed to set_twiddles is >= p */
-    NTT_E_NODEVICE = -8    /* no HIP device / device index out of range */
+    NTT_E_NODEVICE = -8,   /* no HIP device / device index out of range */
+    NTT_E_NOMEM = -9,      /* host memory: a staging buffer (N words) could not be allocated (std::bad_alloc caught at the boundary) */
+    NTT_E_INTERNAL = -10   /* any other C++ exception caught at the boundary (never expected; reported instead of terminating the caller) */
 };
 
 #define NTT_MAX_LOGN 28
@@ -111,6 +120,7 @@ int ntt_plan_get_twiddles(ntt_plan_t plan, int inverse, void *host_T);
  * 3 number of HBM passes of one forward transform (default decomposition), 4 has-inverse-table,
  * 32 + i: stages in pass i, 64 + i: first stage of pass i (pass 0 is the contiguous one);
  * 6 number of decomposition alternatives, 7 forced alternative (-1 = chosen by batch),
+ * 8 the largest number of passes over all alternatives (capacity for ntt_forward_profile),
  * 256 + 16*a + k for alternative a: k = 0 number of passes, k = 1..7 stages in pass k-1,
  * k = 8..14 first stage of pass k-8, k = 15 the smallest batch this alternative is chosen for */
 int64_t ntt_plan_info(ntt_plan_t plan, int what);
@@ -119,7 +129,9 @@ int64_t ntt_plan_info(ntt_plan_t plan, int what);
  * from (N, word size, modulus class) -- the role of the reference's slab-size rule, where the per-tile slab follows from
  * N and the number of cores (src/aie2.py:21-28).  The tables are decomposition-agnostic, so alternatives cost no device
  * memory and every alternative computes the same words.
- *   ntt_plan_select: the alternative ntt_forward / ntt_inverse / ntt_polymul_negacyclic run for `batch` (>= 0).
+ *   ntt_plan_select: the alternative ntt_forward / ntt_inverse / ntt_polymul_negacyclic run for `batch` (>= 0); a product of
+ *   `batch` pairs selects ONCE by `batch` and runs every one of its transforms (also the two-operand launches over 2*batch
+ *   rows) with that decomposition.
  *   ntt_plan_set_policy: alternative = -1 (default) chooses by batch; k >= 0 pins alternative k.  Plan configuration, like
  *   ntt_plan_set_twiddles: call it before the plan is shared between host threads. */
 int ntt_plan_select(ntt_plan_t plan, size_t batch);
@@ -146,7 +158,10 @@ int ntt_forward(ntt_plan_t plan, const void *d_in, void *d_out, size_t batch,
  * trace events, src/aie_core.cc:129-131, src/aie2.py:168,316): identical launches
  * with a hipEvent recorded on `stream` around every HBM pass; blocks until done.
  * Writes the number of passes to *n_passes and their durations to ms_per_pass[]
- * (capacity max_passes). */
+ * (capacity max_passes).  The pass count is that of the alternative chosen for THIS batch
+ * (ntt_plan_select), which can exceed ntt_plan_info(plan, 3) (the default decomposition): size the
+ * array from ntt_plan_info(plan, 8) = the largest pass count over all alternatives (never above 7);
+ * a smaller capacity returns NTT_E_ARG with *n_passes set to the count needed. */
 int ntt_forward_profile(ntt_plan_t plan, const void *d_in, void *d_out, size_t batch,
                         int out_layout, void *stream, float *ms_per_pass, int max_passes,
                         int *n_passes);

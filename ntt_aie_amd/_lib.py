@@ -25,6 +25,8 @@ NTT_E_NOTINVERTIBLE = -5
 NTT_E_LAYOUT = -6
 NTT_E_RANGE = -7
 NTT_E_NODEVICE = -8
+NTT_E_NOMEM = -9
+NTT_E_INTERNAL = -10
 
 LAYOUT_NATURAL = 0
 LAYOUT_AIE_BLOCK16 = 1
@@ -39,7 +41,7 @@ EXPORTS = (
 
 def kernel_source_hash() -> str:
     """16 hex digits over the device-code sources (csrc/*.h, *.inc and the kernel *.hip files; not the host-side C-ABI
-    ntt_api.hip): the identity of the kernels a profile was collected on.  bench.py and tools/*_summary.py stamp it into
+    ntt_api.hip / guard.h): the identity of the kernels a profile was collected on.  bench.py and tools/*_summary.py stamp it into
     what they write, and bench.py refuses to quote counter values whose stamp differs from the tree it runs in."""
     import glob
     import hashlib
@@ -47,7 +49,7 @@ def kernel_source_hash() -> str:
     h = hashlib.sha256()
     src = os.path.join(_HERE, "csrc")
     for f in sorted(glob.glob(os.path.join(src, "*.h")) + glob.glob(os.path.join(src, "*.inc")) + glob.glob(os.path.join(src, "*.hip"))):
-        if os.path.basename(f) == "ntt_api.hip":
+        if os.path.basename(f) in ("ntt_api.hip", "guard.h"):  # host side of the C-ABI: no device code
             continue
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
@@ -131,6 +133,14 @@ def lib() -> C.CDLL:
             import torch  # noqa: F401
         except ImportError:
             pass
+        probe = C.CDLL(LIB_PATH)
+        if not hasattr(probe, "ntt_plan_select"):
+            # a build from before round 3 (tools/regress_sweep.py times one through open_library(path, since_v3=False)):
+            # the package itself needs the launch-time alternatives
+            probe.ntt_version.restype = C.c_int
+            raise ImportError("%s is an older build of the C-ABI (ntt_version() = %d, no ntt_plan_select): the package needs "
+                              "version >= 300; tools that time an old build call _lib.open_library(path, since_v3=False)"
+                              % (LIB_PATH, probe.ntt_version()))
         L = open_library(LIB_PATH)
         if is_experiment_build(L) and not _allow_experiment:
             raise ImportError("%s is an experiment build (-DNTT_EXPERIMENT: its debug switches can skip stores); the product "

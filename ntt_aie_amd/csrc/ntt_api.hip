@@ -7,11 +7,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
 
 #include "../../include/ntt_hip.h"
+#include "guard.h"
 #include "kernels.h"
 #include "plan.h"
 
@@ -106,9 +108,32 @@ struct ntt_plan {
     int forced_alt;                // ntt_plan_set_policy: -1 = by batch, k >= 0 = always alternative k
 };
 
+static_assert(NTT_E_NOMEM == NTT_E_NOMEM_GUARD && NTT_E_INTERNAL == NTT_E_INTERNAL_GUARD, "guard.h codes = include/ntt_hip.h codes");
+
 namespace {
 
 enum { FK_M32 = 0, FK_GL = 1, FK_M64 = 2 };
+
+// frees what a (possibly half-built) plan owns; the device must be current
+void free_plan(ntt_plan *pl) {
+    if (!pl) return;
+    if (pl->d_tw_fwd) (void) hipFree(pl->d_tw_fwd);
+    if (pl->d_tw_inv) (void) hipFree(pl->d_tw_inv);
+    if (pl->d_tw_inv_sc) (void) hipFree(pl->d_tw_inv_sc);
+    if (pl->d_fused_ctl) (void) hipFree(pl->d_fused_ctl);
+    if (pl->d_counter) (void) hipFree(pl->d_counter);
+    delete pl;
+}
+// ntt_plan_create builds the plan under this holder: an exception (std::bad_alloc from the alternatives' vectors)
+// unwinds through it, so the guard's error return leaks neither the struct nor device memory
+struct PlanDeleter {
+    void operator()(ntt_plan *pl) const {
+        if (!pl) return;
+        DeviceGuard g(pl->device);
+        free_plan(pl);
+    }
+};
+using PlanHolder = std::unique_ptr<ntt_plan, PlanDeleter>;
 
 hipError_t launch_fwd(const ntt_plan *pl, const PassDesc &pd, const ntt::ErasedArgs &a, hipStream_t s) {
     return pl->fk == FK_GL ? ntt::launch_gl_fwd(pd.contig, pd.log_m, a, s)
@@ -161,8 +186,9 @@ int check_io(const ntt_plan *pl, const void *a, const void *b, size_t batch) {
 
 // in2 != null: transform in[j] * in2[j] * pw_scale (plain) instead of in[j]; the product is folded into
 // the load of the first pass
+// `forced`: the decomposition to run (a product picks ONE for all of its transforms); null = passes_for(batch)
 int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int layout, hipStream_t s,
-                const void *in2 = nullptr, uint64_t pw_scale_plain = 1) {
+                const void *in2 = nullptr, uint64_t pw_scale_plain = 1, const std::vector<PassDesc> *forced = nullptr) {
     RoctxRange whole(in2 ? "ntt_forward(product)" : "ntt_forward");
     const void *src = d_in;
     const void *skip_if = nullptr;
@@ -177,7 +203,7 @@ int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
         if (pl->dbg & (16 | 32 | 64)) return NTT_OK;  // timing experiments: fused launch alone
     }
 #endif
-    const std::vector<PassDesc> &passes = passes_for(pl, batch);
+    const std::vector<PassDesc> &passes = forced ? *forced : passes_for(pl, batch);
     for (const PassDesc &pd : passes) {
 #if defined(NTT_EXPERIMENT)
         if (pl->only_pass >= 0 && (int) (&pd - &passes.front()) != pl->only_pass) continue;  // timing experiment: outputs meaningless
@@ -199,10 +225,10 @@ int run_forward(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
 }
 
 int run_inverse(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int layout, int scale,
-                hipStream_t s) {
+                hipStream_t s, const std::vector<PassDesc> *forced = nullptr) {
     RoctxRange whole("ntt_inverse");
     const void *src = d_in;
-    const std::vector<PassDesc> &passes = passes_for(pl, batch);
+    const std::vector<PassDesc> &passes = forced ? *forced : passes_for(pl, batch);
     for (size_t i = passes.size(); i-- > 0;) {
         const PassDesc &pd = passes[i];
         RoctxRange pass("inv pass", pd.contig, pd.s0, pd.log_m);
@@ -224,17 +250,17 @@ int run_inverse(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
 
 extern "C" {
 
-int ntt_version(void) { return 300; /* 0.3.0 */ }
+int ntt_version(void) { return 400; /* 0.4.0 */ }
 
 #if defined(NTT_EXPERIMENT)
 // libntt_hip_exp.so only (never declared in include/ntt_hip.h, never exported by the product): the timing switches of
 // PassArgs::dbg for ONE plan, set explicitly instead of through the process environment (bench.py's VALU-floor leg).
 // The symbol doubles as the build's identity: ntt_aie_amd/_lib.py refuses a library that exports it.
-int ntt_plan_set_debug(ntt_plan_t pl, int flags) {
+int ntt_plan_set_debug(ntt_plan_t pl, int flags) NTT_GUARD {
     if (!pl) return NTT_E_ARG;
     pl->dbg = flags;
     return NTT_OK;
-}
+} NTT_GUARD_END
 #endif
 
 const char *ntt_error_string(int code) {
@@ -248,6 +274,8 @@ const char *ntt_error_string(int code) {
         case NTT_E_LAYOUT: return "AIE_BLOCK16 layout needs N >= 16";
         case NTT_E_RANGE: return "twiddle out of range [0, p)";
         case NTT_E_NODEVICE: return "no such HIP device";
+        case NTT_E_NOMEM: return "out of host memory (a staging buffer of N words could not be allocated)";
+        case NTT_E_INTERNAL: return "internal error (a C++ exception was caught at the C boundary)";
         default: break;
     }
     if (code > 0) return hipGetErrorString((hipError_t) code);
@@ -260,7 +288,7 @@ int ntt_device_count(void) {
     return n;
 }
 
-int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int device) {
+int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int device) NTT_GUARD {
     if (!out) return NTT_E_ARG;
     *out = nullptr;
     if (word_bytes != 4 && word_bytes != 8) return NTT_E_ARG;
@@ -269,13 +297,16 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     if (word_bytes == 4 && p > 0xFFFFFFFFull) return NTT_E_PRIME;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return NTT_E_NODEVICE;
-    ntt_plan *pl = new (std::nothrow) ntt_plan();
-    if (!pl) return NTT_E_ARG;
+    PlanHolder holder(new (std::nothrow) ntt_plan());
+    ntt_plan *pl = holder.get();
+    if (!pl) return NTT_E_NOMEM;
+    pl->d_tw_fwd = pl->d_tw_inv = pl->d_tw_inv_sc = nullptr;
+    pl->d_fused_ctl = nullptr;
+    pl->d_counter = nullptr;
+    pl->device = device;
     pl->logn = logn;
     pl->p = p;
     pl->word_bytes = word_bytes;
-    pl->device = device;
-    pl->d_tw_fwd = pl->d_tw_inv = pl->d_tw_inv_sc = nullptr;
     pl->has_table = pl->has_inv = false;
     pl->pinv = pl->r2 = 0;
     pl->pinv64 = pl->r2_64 = 0;
@@ -295,9 +326,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     pl->dbg = 0;
     pl->only_pass = -1;
     pl->fused = 0;
-    pl->d_fused_ctl = nullptr;
     pl->fused_max_batch = 0;
-    pl->d_counter = nullptr;
     pl->alts = plan_alternatives(logn, word_bytes, p);
     pl->passes = pl->alts[0].passes;
     pl->forced_alt = -1;
@@ -337,10 +366,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     }
 #endif
     DeviceGuard g(device);
-    if (g.err != hipSuccess) {
-        delete pl;
-        return (int) g.err;
-    }
+    if (g.err != hipSuccess) return (int) g.err;
     hipError_t e = hipMalloc(&pl->d_tw_fwd, table_bytes(pl));
     if (e == hipSuccess) e = hipMalloc(&pl->d_tw_inv, table_bytes(pl));
     if (e == hipSuccess && sc_table_bytes(pl)) e = hipMalloc(&pl->d_tw_inv_sc, sc_table_bytes(pl));
@@ -351,31 +377,19 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
         e = hipMalloc(&pl->d_fused_ctl, ntt::fused_gl16_ctl_bytes(pl->fused_max_batch));
     }
 #endif
-    if (e != hipSuccess) {
-        if (pl->d_tw_fwd) (void) hipFree(pl->d_tw_fwd);
-        if (pl->d_tw_inv) (void) hipFree(pl->d_tw_inv);
-        if (pl->d_tw_inv_sc) (void) hipFree(pl->d_tw_inv_sc);
-        if (pl->d_counter) (void) hipFree(pl->d_counter);
-        delete pl;
-        return (int) e;
-    }
-    *out = pl;
+    if (e != hipSuccess) return (int) e;  // the holder frees what was allocated
+    *out = holder.release();
     return NTT_OK;
-}
+} NTT_GUARD_END
 
-int ntt_plan_destroy(ntt_plan_t pl) {
+int ntt_plan_destroy(ntt_plan_t pl) NTT_GUARD {
     if (!pl) return NTT_E_ARG;
     DeviceGuard g(pl->device);
-    if (pl->d_tw_fwd) (void) hipFree(pl->d_tw_fwd);
-    if (pl->d_tw_inv) (void) hipFree(pl->d_tw_inv);
-    if (pl->d_tw_inv_sc) (void) hipFree(pl->d_tw_inv_sc);
-    if (pl->d_fused_ctl) (void) hipFree(pl->d_fused_ctl);
-    if (pl->d_counter) (void) hipFree(pl->d_counter);
-    delete pl;
+    free_plan(pl);
     return NTT_OK;
-}
+} NTT_GUARD_END
 
-int ntt_plan_set_twiddles(ntt_plan_t pl, const void *host_T) {
+int ntt_plan_set_twiddles(ntt_plan_t pl, const void *host_T) NTT_GUARD {
     if (!pl || !host_T) return NTT_E_ARG;
     const size_t N = (size_t) 1 << pl->logn;
     const uint64_t p = pl->p;
@@ -411,9 +425,9 @@ int ntt_plan_set_twiddles(ntt_plan_t pl, const void *host_T) {
     pl->has_table = true;
     pl->has_inv = inv_ok;
     return NTT_OK;
-}
+} NTT_GUARD_END
 
-int ntt_make_table(ntt_plan_t pl, int kind, uint64_t g, void *host_T) {
+int ntt_make_table(ntt_plan_t pl, int kind, uint64_t g, void *host_T) NTT_GUARD {
     if (!pl || !host_T) return NTT_E_ARG;
     const uint64_t N = 1ull << pl->logn;
     std::vector<uint64_t> T;
@@ -423,9 +437,9 @@ int ntt_make_table(ntt_plan_t pl, int kind, uint64_t g, void *host_T) {
         else ((uint64_t *) host_T)[i] = T[i];
     }
     return NTT_OK;
-}
+} NTT_GUARD_END
 
-int ntt_plan_generate_twiddles(ntt_plan_t pl, int kind, uint64_t g) {
+int ntt_plan_generate_twiddles(ntt_plan_t pl, int kind, uint64_t g) NTT_GUARD {
     if (!pl || kind < 0 || kind > 2) return NTT_E_ARG;
     const uint64_t N = 1ull << pl->logn, p = pl->p;
     uint64_t base;
@@ -469,9 +483,9 @@ int ntt_plan_generate_twiddles(ntt_plan_t pl, int kind, uint64_t g) {
     pl->has_table = true;
     pl->has_inv = true;  // every entry is a power of a unit
     return NTT_OK;
-}
+} NTT_GUARD_END
 
-int ntt_plan_get_twiddles(ntt_plan_t pl, int inverse, void *host_T) {
+int ntt_plan_get_twiddles(ntt_plan_t pl, int inverse, void *host_T) NTT_GUARD {
     if (!pl || !host_T) return NTT_E_ARG;
     if (!pl->has_table) return NTT_E_NOTABLE;
     if (inverse && !pl->has_inv) return NTT_E_NOTINVERTIBLE;
@@ -488,11 +502,11 @@ int ntt_plan_get_twiddles(ntt_plan_t pl, int inverse, void *host_T) {
         else ((uint64_t *) host_T)[i] = mulmod(((uint64_t *) host_T)[i], rinv, p);
     }
     return NTT_OK;
-}
+} NTT_GUARD_END
 
-int ntt_make_roots(ntt_plan_t pl, uint64_t g, void *host_T) { return ntt_make_table(pl, 0, g, host_T); }
+int ntt_make_roots(ntt_plan_t pl, uint64_t g, void *host_T) NTT_GUARD { return ntt_make_table(pl, 0, g, host_T); } NTT_GUARD_END
 
-int64_t ntt_plan_info(ntt_plan_t pl, int what) {
+int64_t ntt_plan_info(ntt_plan_t pl, int what) NTT_GUARD {
     if (!pl) return NTT_E_ARG;
     switch (what) {
         case 0: return pl->logn;
@@ -503,6 +517,11 @@ int64_t ntt_plan_info(ntt_plan_t pl, int what) {
         case 5: return pl->d_fused_ctl ? 1 : 0;
         case 6: return (int64_t) pl->alts.size();
         case 7: return pl->forced_alt;
+        case 8: {  // capacity for ntt_forward_profile whatever the batch
+            size_t k = 0;
+            for (const PlanAlt &a : pl->alts) k = a.passes.size() > k ? a.passes.size() : k;
+            return (int64_t) k;
+        }
         default: break;
     }
     if (what >= 256 && what < 256 + 16 * (int) pl->alts.size()) {
@@ -525,20 +544,20 @@ int64_t ntt_plan_info(ntt_plan_t pl, int what) {
     }
 #endif
     return NTT_E_ARG;
-}
+} NTT_GUARD_END
 
-int ntt_plan_select(ntt_plan_t pl, size_t batch) {
+int ntt_plan_select(ntt_plan_t pl, size_t batch) NTT_GUARD {
     if (!pl) return NTT_E_ARG;
     return pl->forced_alt >= 0 ? pl->forced_alt : select_alternative(pl->alts, batch);
-}
+} NTT_GUARD_END
 
-int ntt_plan_set_policy(ntt_plan_t pl, int alternative) {
+int ntt_plan_set_policy(ntt_plan_t pl, int alternative) NTT_GUARD {
     if (!pl || alternative < -1 || alternative >= (int) pl->alts.size()) return NTT_E_ARG;
     pl->forced_alt = alternative;
     return NTT_OK;
-}
+} NTT_GUARD_END
 
-int ntt_plan_clone(ntt_plan_t src, int device, ntt_plan_t *out) {
+int ntt_plan_clone(ntt_plan_t src, int device, ntt_plan_t *out) NTT_GUARD {
     if (!out) return NTT_E_ARG;
     *out = nullptr;
     if (!src) return NTT_E_ARG;
@@ -575,9 +594,9 @@ int ntt_plan_clone(ntt_plan_t src, int device, ntt_plan_t *out) {
     }
     *out = pl;
     return NTT_OK;
-}
+} NTT_GUARD_END
 
-int ntt_forward(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int out_layout, void *stream) {
+int ntt_forward(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int out_layout, void *stream) NTT_GUARD {
     int rc = check_io(pl, d_in, d_out, batch);
     if (rc) return rc;
     if (!pl->has_table) return NTT_E_NOTABLE;
@@ -587,16 +606,16 @@ int ntt_forward(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int 
     DeviceGuard g(pl->device);
     if (g.err != hipSuccess) return (int) g.err;
     return run_forward(pl, d_in, d_out, batch, out_layout, (hipStream_t) stream);
-}
+} NTT_GUARD_END
 
 int ntt_forward_profile(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int out_layout,
-                        void *stream, float *ms_per_pass, int max_passes, int *n_passes) {
+                        void *stream, float *ms_per_pass, int max_passes, int *n_passes) NTT_GUARD {
     int rc = check_io(pl, d_in, d_out, batch);
     if (rc) return rc;
     if (!ms_per_pass || !n_passes) return NTT_E_ARG;
     const std::vector<PassDesc> &passes = passes_for(pl, batch);
-    if (max_passes < (int) passes.size()) return NTT_E_ARG;
     *n_passes = (int) passes.size();
+    if (max_passes < (int) passes.size()) return NTT_E_ARG;
     if (!pl->has_table) return NTT_E_NOTABLE;
     if (batch == 0) return NTT_OK;
     DeviceGuard g(pl->device);
@@ -629,10 +648,10 @@ int ntt_forward_profile(ntt_plan_t pl, const void *d_in, void *d_out, size_t bat
     for (size_t i = 0; i < np && e == hipSuccess; i++) e = hipEventElapsedTime(&ms_per_pass[i], ev[i], ev[i + 1]);
     for (auto &x : ev) (void) hipEventDestroy(x);
     return (int) e;
-}
+} NTT_GUARD_END
 
 int ntt_inverse(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int in_layout, int scale,
-                void *stream) {
+                void *stream) NTT_GUARD {
     int rc = check_io(pl, d_in, d_out, batch);
     if (rc) return rc;
     if (!pl->has_table) return NTT_E_NOTABLE;
@@ -643,10 +662,10 @@ int ntt_inverse(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int 
     DeviceGuard g(pl->device);
     if (g.err != hipSuccess) return (int) g.err;
     return run_inverse(pl, d_in, d_out, batch, in_layout, scale, (hipStream_t) stream);
-}
+} NTT_GUARD_END
 
 int ntt_pointwise_mul(ntt_plan_t pl, const void *d_a, const void *d_b, void *d_out, size_t batch,
-                      uint64_t scale, void *stream) {
+                      uint64_t scale, void *stream) NTT_GUARD {
     int rc = check_io(pl, d_a, d_b, batch);
     if (rc) return rc;
     if (batch && (!d_out || ((uintptr_t) d_out & 15u))) return NTT_E_ARG;
@@ -661,9 +680,9 @@ int ntt_pointwise_mul(ntt_plan_t pl, const void *d_a, const void *d_b, void *d_o
                                       : ntt::launch_pointwise_m32(d_a, d_b, d_out, count, (uint32_t) pl->p, pl->pinv,
                                                                   pl->r2, (uint32_t) scale, (hipStream_t) stream);
     return (int) e;
-}
+} NTT_GUARD_END
 
-int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, size_t batch, void *stream) {
+int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, size_t batch, void *stream) NTT_GUARD {
     int rc = check_io(pl, d_a, d_b, batch);
     if (rc) return rc;
     if (batch && (!d_out || ((uintptr_t) d_out & 15u))) return NTT_E_ARG;
@@ -736,19 +755,20 @@ int ntt_polymul_negacyclic(ntt_plan_t pl, void *d_a, void *d_b, void *d_out, siz
     }
     if (contiguous) {
         // the operands are one [2*batch][N] buffer: both unscaled inverse transforms as ONE launch per pass
-        rc = run_inverse(pl, d_a, d_a, 2 * batch, NTT_LAYOUT_NATURAL, 0, s);
+        // (the decomposition is the one selected for `batch`, as ntt_plan_select documents -- not for the 2*batch rows of this launch)
+        rc = run_inverse(pl, d_a, d_a, 2 * batch, NTT_LAYOUT_NATURAL, 0, s, &passes);
         if (rc) return rc;
     } else {
-        rc = run_inverse(pl, d_a, d_a, batch, NTT_LAYOUT_NATURAL, 0, s);
+        rc = run_inverse(pl, d_a, d_a, batch, NTT_LAYOUT_NATURAL, 0, s, &passes);
         if (rc) return rc;
-        rc = run_inverse(pl, d_b, d_b, batch, NTT_LAYOUT_NATURAL, 0, s);
+        rc = run_inverse(pl, d_b, d_b, batch, NTT_LAYOUT_NATURAL, 0, s, &passes);
         if (rc) return rc;
     }
     // pointwise product * N^-1 folded into the first pass of the final forward transform
-    return run_forward(pl, d_a, d_out, batch, NTT_LAYOUT_NATURAL, s, d_b, pl->ninv_plain);
-}
+    return run_forward(pl, d_a, d_out, batch, NTT_LAYOUT_NATURAL, s, d_b, pl->ninv_plain, &passes);
+} NTT_GUARD_END
 
-int ntt_count_noncanonical(ntt_plan_t pl, const void *d_buf, size_t batch, uint64_t *host_count) {
+int ntt_count_noncanonical(ntt_plan_t pl, const void *d_buf, size_t batch, uint64_t *host_count) NTT_GUARD {
     if (!pl || !host_count) return NTT_E_ARG;
     *host_count = 0;
     if (batch == 0) return NTT_OK;
@@ -763,9 +783,9 @@ int ntt_count_noncanonical(ntt_plan_t pl, const void *d_buf, size_t batch, uint6
     if (e == hipSuccess) e = hipMemcpy(&h, d_cnt, sizeof(h), hipMemcpyDeviceToHost);
     *host_count = h;
     return (int) e;
-}
+} NTT_GUARD_END
 
-int ntt_forward_stages(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int stage, void *stream) {
+int ntt_forward_stages(ntt_plan_t pl, const void *d_in, void *d_out, size_t batch, int stage, void *stream) NTT_GUARD {
     int rc = check_io(pl, d_in, d_out, batch);
     if (rc) return rc;
     if (!pl->has_table) return NTT_E_NOTABLE;
@@ -787,6 +807,6 @@ int ntt_forward_stages(ntt_plan_t pl, const void *d_in, void *d_out, size_t batc
         if (e != hipSuccess) return (int) e;
     }
     return NTT_OK;
-}
+} NTT_GUARD_END
 
 }  // extern "C"

@@ -34,8 +34,10 @@ def test_error_contract_without_compute(hiplib):
     L = hiplib.lib()
     assert L.ntt_version() >= 100
     assert L.ntt_error_string(0) == b"ok"
-    for code in range(-8, 0):
+    for code in range(-10, 0):
         assert L.ntt_error_string(code) not in (None, b"", b"unknown error")
+    assert L.ntt_error_string(-11) == b"unknown error"
+    assert (hiplib.NTT_E_NOMEM, hiplib.NTT_E_INTERNAL) == (-9, -10)
     h = C.c_void_p()
     # argument errors are reported before any device is touched
     assert L.ntt_plan_create(None, 8, 3329, 4, 0) == hiplib.NTT_E_ARG
@@ -50,6 +52,48 @@ def test_error_contract_without_compute(hiplib):
     assert L.ntt_plan_destroy(None) == hiplib.NTT_E_ARG
     if L.ntt_device_count() == 0:
         assert L.ntt_plan_create(C.byref(h), 8, 3329, 4, 0) == hiplib.NTT_E_NODEVICE
+
+
+# entry points that cannot throw and have no error code to return: a constant, a switch over string literals,
+# one runtime call returning a count ("never fails": 0 devices on error)
+UNGUARDED = {"ntt_version", "ntt_error_string", "ntt_device_count"}
+
+
+def test_every_entry_point_is_behind_the_exception_wall():
+    """include/ntt_hip.h: "nothing throws or aborts".  By parsing the source: every function defined in ntt_api.hip's
+    extern "C" block that the header declares is a function-try-block -- its body opens with NTT_GUARD and closes with
+    NTT_GUARD_END (csrc/guard.h: std::bad_alloc -> NTT_E_NOMEM, anything else -> NTT_E_INTERNAL) -- and no `new` outside
+    std::nothrow, no abort()/exit()/assert() sits in the file."""
+    api = open(os.path.join(ROOT, "ntt_aie_amd", "csrc", "ntt_api.hip")).read()
+    ext = api[api.index('extern "C" {'):]
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ntt_hip.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(ntt_[a-z_0-9]+)\s*\(", hdr))
+    defs = re.findall(r"^(?:int|int64_t|const char \*)\s*(ntt_[a-z_0-9]+)\(([^{;]*?)\)\s*(NTT_GUARD )?\{", ext, flags=re.M | re.S)
+    seen = {}
+    for name, _, guard in defs:
+        seen[name] = bool(guard)
+    assert declared <= set(seen), declared - set(seen)
+    for name in sorted(declared):
+        if name in UNGUARDED:
+            continue
+        assert seen[name], "%s is not behind NTT_GUARD" % name
+    # every opened guard is closed, once
+    assert ext.count("NTT_GUARD {") == ext.count("} NTT_GUARD_END") == sum(seen.values())
+    body = re.sub(r"//.*", "", api)
+    assert not re.search(r"\b(abort|exit|assert)\s*\(", body)
+    assert re.findall(r"\bnew\b(?!\s*\(std::nothrow\))", re.sub(r"#include <new>", "", body)) == []
+
+
+def test_guard_macros_convert_exceptions(tmp_path):
+    """csrc/guard.h on the CPU (tests/cxx/guard_test.cpp, g++): bad_alloc -- thrown, and from a real oversized std::vector --
+    comes back as NTT_E_NOMEM (-9); length_error, a thrown int, runtime_error as NTT_E_INTERNAL (-10); values pass through."""
+    import subprocess
+
+    exe = str(tmp_path / "guard_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cxx", "guard_test.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["plain=42", "bad_alloc=-9", "vector=-9", "length=-10", "int=-10", "wide=-10"], out.stdout
 
 
 def test_product_has_no_oracle_dependency():

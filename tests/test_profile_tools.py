@@ -48,6 +48,53 @@ def test_parse_pass_kernel_full_argument_list():
     assert parse_pass_kernel(OTHER) is None
 
 
+def kname_sc(log_m, log_c, contig, inv, log_e, sc):
+    """Round 3's kernel names: pass_kernel<Cfg, SC>."""
+    cfg = "ntt::PassCfg<ntt::FieldGL, %d, %d, %s, %s, 15, %d, 8, true>" % (log_m, log_c, str(contig).lower(), str(inv).lower(), log_e)
+    return "void ntt::(anonymous namespace)::pass_kernel<%s, %s>(ntt::PassArgs<%s >)" % (cfg, str(sc).lower(), cfg)
+
+
+def test_scaled_and_unscaled_inverse_kernels_are_two_keys(tmp_path):
+    """pass_kernel<Cfg, true> (N^-1 folded into stage 0) and pass_kernel<Cfg, false> of ONE PassCfg are different kernels:
+    two keys, two short names, never averaged (sq_summary) nor overwritten (pmc_summary); a stored key parses back."""
+    import pmc_summary
+    import sq_summary
+    from kernel_key import forward_entry, parse_pass_kernel
+
+    plain, scaled = kname_sc(8, 0, True, True, 3, False), kname_sc(8, 0, True, True, 3, True)
+    a, b = parse_pass_kernel(plain), parse_pass_kernel(scaled)
+    assert not a["sc"] and b["sc"] and a["cfg"] == b["cfg"] and a["key"] != b["key"]
+    assert a["short"] == "pass_contig_8_inv" and b["short"] == "pass_contig_8_inv_sc"
+    assert a["key"] == "PassCfg<ntt::FieldGL, 8, 0, true, true, 15, 3, 8, true>" and b["key"] == a["key"] + " +SC"
+    back = parse_pass_kernel("pass_kernel<" + b["key"])  # how forward_entry() re-parses a stored key
+    assert back["sc"] and back["key"] == b["key"] and back["inv"]
+    fwd = kname_sc(8, 0, True, False, 3, False)
+    assert parse_pass_kernel(fwd)["key"] == "PassCfg<ntt::FieldGL, 8, 0, true, false, 15, 3, 8, true>"  # forward keys unchanged
+    wave_bf = 4096 * 32768 * 8 / 64
+    rows = []
+    for name, ipb in ((plain, 21.0), (scaled, 24.0), (fwd, 23.0)):
+        for rep in range(2):
+            rows.append((name, 2097152, "SQ_INSTS_VALU", ipb * wave_bf, 1000, 801000))
+            rows.append((name, 2097152, "GRBM_GUI_ACTIVE", 8 * 1.6e6, 1000, 801000))
+    p = tmp_path / "sq.csv"
+    write_csv(p, rows)
+    d = sq_summary.summarize(str(p), batch=4096, logn=16, src_hash="abc")
+    by_short = {v["short"]: v for v in d["kernels"].values()}
+    assert set(by_short) == {"pass_contig_8_inv", "pass_contig_8_inv_sc", "pass_contig_8_fwd"}
+    assert by_short["pass_contig_8_inv"]["valu_instr_per_butterfly"] == pytest.approx(21.0)
+    assert by_short["pass_contig_8_inv_sc"]["valu_instr_per_butterfly"] == pytest.approx(24.0)
+    hit, why = forward_entry(d["kernels"], True, 8)
+    assert why is None and hit[1]["short"] == "pass_contig_8_fwd"
+    kib = 4 * 1024 * 1024
+    fr = [(n, 2097152, "FETCH_SIZE", kib / 4 + x, 1, 2) for n, x in ((plain, 0), (scaled, 512))]
+    wr = [(n, 2097152, "WRITE_SIZE", kib / 2 + x, 1, 2) for n, x in ((plain, 0), (scaled, 512))]
+    pf, pw = tmp_path / "f.csv", tmp_path / "w.csv"
+    write_csv(pf, fr)
+    write_csv(pw, wr)
+    t = pmc_summary.summarize(str(pf), str(pw), src_hash="abc")
+    assert len(t["kernels"]) == 2 and len({v["hbm_bytes_per_launch"] for v in t["kernels"].values()}) == 2
+
+
 def test_sq_summary_keeps_directions_apart(tmp_path):
     import sq_summary
 

@@ -5,6 +5,9 @@ overwrote / mixed into the forward kernels' keys ("What's weak" 1).
 through this one parser, and a CPU unit test (tests/test_profile_tools.py) feeds it a CSV holding both directions.
 
 PassCfg template arguments (csrc/pass.h): <F, LOG_M, LOG_C, CONTIG, INV, PRELOAD_MASK, LOG_E, LOG_NT, ALLOW_DMA>.
+pass_kernel has a second template argument since round 3: pass_kernel<Cfg, SC>, SC = true for the scaled inverse whose N^-1 is
+folded into stage 0 (a different kernel: other registers, N/2 more products).  SC is part of the key (round 4; before, the two
+inverse kernels of one shape were averaged together).
 """
 from __future__ import annotations
 
@@ -13,10 +16,16 @@ FIELDS = ("field", "log_m", "log_c", "contig", "inv", "preload_mask", "log_e", "
 
 def parse_pass_kernel(name: str):
     """{'cfg': normalised argument list, 'field', 'log_m', 'contig', 'inv', ..., 'key', 'short'} or None when `name` is not a
-    pass kernel.  `key` = the full argument list (unique per instantiation); `short` = pass_<contig|col>_<LOG_M>_<fwd|inv>."""
+    pass kernel.  `key` = the full argument list, plus " +SC" for pass_kernel<Cfg, true> (unique per instantiation);
+    `short` = pass_<contig|col>_<LOG_M>_<fwd|inv>[_sc]."""
     if "pass_kernel<" not in name or "PassCfg<" not in name:
         return None
-    args = [a.strip() for a in name.split("PassCfg<", 1)[1].split(">", 1)[0].split(",")]
+    rest = name.split("PassCfg<", 1)[1]
+    args = [a.strip() for a in rest.split(">", 1)[0].split(",")]
+    # what follows the first PassCfg<...>: ", true>(" / ", false>(" in a demangled kernel name; nothing in a stored key
+    tail = rest.split(">", 1)[1].lstrip() if ">" in rest else ""
+    sc = tail.startswith(",") and tail[1:].lstrip().startswith("true")
+    sc = sc or tail.startswith("+SC")
     if len(args) < 5:
         return None
     d = dict(zip(FIELDS, args))
@@ -30,8 +39,10 @@ def parse_pass_kernel(name: str):
         "log_e": int(d["log_e"]) if "log_e" in d else None,
         "log_nt": int(d["log_nt"]) if "log_nt" in d else None,
     }
-    out["key"] = out["cfg"]
-    out["short"] = "pass_%s_%d_%s" % ("contig" if out["contig"] else "col", out["log_m"], "inv" if out["inv"] else "fwd")
+    out["sc"] = bool(sc)
+    out["key"] = out["cfg"] + (" +SC" if sc else "")
+    out["short"] = "pass_%s_%d_%s%s" % ("contig" if out["contig"] else "col", out["log_m"], "inv" if out["inv"] else "fwd",
+                                        "_sc" if sc else "")
     return out
 
 
