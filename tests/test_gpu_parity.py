@@ -436,6 +436,9 @@ def test_bench_two_ranks_rehearsal():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 256 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6  # whole-job aggregate
     assert "cpu_baseline" not in d  # rank 0 at N=1 only
+    # round 4: no time without a check -- every rank verified its own shard and named its device
+    assert d["all_ranks_verified"] is True and d["world_size_seen"] == 2 and [r["rank"] for r in d["ranks"]] == [0, 1]
+    assert all(r["round_trip_identical"] and r["coefficient_sum_invariant"] and r["ms_per_step"] > 0 for r in d["ranks"])
 
 
 def test_large_sizes_against_oracle(eng, oracle):

@@ -131,9 +131,12 @@ def test_product_under_every_alternative(eng, oracle, wb, p, g, logn):
         assert np.array_equal(c, e), k
 
 
-@pytest.mark.parametrize("wb,p,g", [(8, GOLD, 7), (4, 3221225473, 5), (4, 998244353, 3)])
+@pytest.mark.parametrize("wb,p,g", [(8, GOLD, 7), (4, 3221225473, 5), (4, 998244353, 3),
+                                     (8, 0x3FFFFFEE00000001, 3), (8, 0xFFFFFFFC00000001, 10)])
 def test_two_pass_2p22_nine_stage_column_pass(eng, oracle, wb, p, g):
-    """N = 2^22 = 13 + 9: the 512-row column tile (512 / 1024 threads), forward / inverse / block order, ragged batch."""
+    """N = 2^22 = 13 + 9: the 512-row column tile (512 / 1024 threads), forward / inverse / block order, ragged batch.
+    Round 4: the general 64-bit modulus too -- ColCfg<9, FieldM64> in 512 threads under the 128-VGPR cap with
+    the m64 streams' pinned scratch, and the forward ContigCfg13<FieldM64>, had only host-model coverage."""
     dt = np.uint32 if wb == 4 else np.uint64
     logn, n = 22, 1 << 22
     T = oracle.make_roots(n, p, g, wb)
@@ -275,6 +278,7 @@ def test_bench_self_launch_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 256 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+    assert d["all_ranks_verified"] is True and d["world_size_seen"] == 2 and len(d["ranks"]) == 2  # round 4: every rank checked
     # config 5 is named when its per-GPU batch is asked for
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                           "--batch", "8192"], capture_output=True, text=True, timeout=900, env=env)
@@ -322,6 +326,13 @@ def test_general_64bit_modulus(eng, oracle, p, g):
         b = a.copy()
         b[1, 7] = p
         assert pl.count_noncanonical(eng.to_device(b, "cuda:0")) == 1
+    # N = 2^21 = 13 + 8: the forward 13-stage CONTIG kernel of FieldM64 on the device, every leg
+    logn = 21
+    T = oracle.make_roots(1 << logn, p, g, 8)
+    pl = eng.NTTPlan(logn, p, 8, 0)
+    pl.set_twiddles(T)
+    assert [m for _, _, m in pl.passes] == [13, 8]
+    _check_all_legs(eng, oracle, pl, T, p, dt, (1, 3), seed=logn)
     # negacyclic product (kind-2 table; the fused middle pass instantiated for FieldM64, as for Goldilocks) and pointwise
     for logn in (6, 12, 14, 17, 20):  # 2^6: pointwise folded into the forward pass; 2^12: ONE fused launch; 2^14 / 2^17 / 2^20: fused middle of 8 / 9 / 12 stages
         n = 1 << logn
@@ -363,8 +374,9 @@ def test_general_64bit_modulus_any_odd(eng, oracle):
 
 
 def test_bench_quotes_only_matching_forward_counters():
-    """The headline bench line quotes hardware counters from profiles/r03_*.json only when their kernel-source hash equals the
-    tree's, and then only the FORWARD kernels' entries (INV argument false); otherwise it says why not."""
+    """The headline bench line quotes hardware counters from profiles/<round>_*.json only when their kernel-source hash equals
+    the tree's, and then only the FORWARD kernels' entries (INV argument false); otherwise it says why not."""
+    import bench
     from ntt_aie_amd import _lib
 
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
@@ -373,12 +385,15 @@ def test_bench_quotes_only_matching_forward_counters():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     r = d["roofline"]
     assert d["config"]["baseline_config"] == 3 and "inverse" not in d
-    stamped = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["src_hash"]
+    path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % bench.PROFILE_ROUND)
+    stamped = json.load(open(path))["src_hash"] if os.path.exists(path) else None
     if stamped == _lib.kernel_source_hash():
         assert r["traffic"] is not None and 1.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 2.1  # two trips, no over-fetch
         assert "forward kernels" in r["traffic_source"] and ", true," not in r["traffic_source"].split("forward kernels:")[1].replace("true, false", "")
         v = r["valu"]
         assert v is not None and all(20 < x < 26 for x in v["instr_per_butterfly"]) and 0 < v["frac_at_held_clock"] <= 1
         assert all("false" in k.split(",")[4] for k in v["kernels"])  # PassCfg<F, LOG_M, LOG_C, CONTIG, INV, ...>: INV == false
+        if v.get("issue_model"):  # the weighted figure rides on the same counters
+            assert 0 < v["frac_at_held_clock_weighted"] < 1.2 and len(v["issue_cycles_per_butterfly_weighted"]) == 2
     else:
-        assert r["traffic"] is None and r["valu"] is None and "not quoted" in r["traffic_source"]
+        assert r["traffic"] is None and r["valu"] is None and ("not quoted" in r["traffic_source"] or "absent" in r["traffic_source"])
