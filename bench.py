@@ -479,9 +479,13 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
     out["step_ms_median"] = step_ms[len(step_ms) // 2]
     out["step_ms_min"] = step_ms[0]
     # roofline: per-pass kernel durations from hipEvents on the launch stream
+    # (ntt_forward_profile blocks until its last event: two plain transforms are queued ahead of every profiled one, so the
+    # profiled passes run behind a busy GPU at the clock the timed region held, not on a chip ramping up from idle)
     reps = max(5, min(args.steps, 20))
     per_pass = np.zeros(len(passes))
     for _ in range(reps):
+        plan.forward(x, y, stream=stream)
+        plan.forward(x, y, stream=stream)
         per_pass += np.array(plan.forward_profile(x, y, stream=stream))
     per_pass /= reps
     alg_bytes = 2.0 * n * 8 * batch  # 2*N*sizeof(word) per transform, read once + write once
@@ -532,8 +536,11 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
         "frac_ceiling": 1.0 / len(passes),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        # the same bytes over the step time the line's own `value` is made of (launch gaps included): never above `frac`
+        # the same bytes over the step time the line's own `value` is made of (launch gaps included).  A step cannot be shorter
+        # than its kernels, so frac_step is capped at frac; the two are measured seconds apart, and when the uncapped quotient
+        # (frac_step_uncapped) comes out above frac the difference is the clock the chip held in each phase, not a faster step
         "frac_step": min(alg_bytes / step_s / 1e9, achieved) / HBM_PEAK_GBS,
+        "frac_step_uncapped": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
         "achieved_step": alg_bytes / step_s / 1e9,
         "traffic": traffic, "traffic_source": traffic_src,
         "definition": "algorithmic bytes of one forward transform (2*N*8 B) x batch / summed duration of its "

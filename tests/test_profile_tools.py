@@ -165,3 +165,69 @@ def test_pmc_summary_keeps_directions_apart(tmp_path):
 
     ent, why = bench.forward_counters(d, [("contig", 0, 8), ("col", 8, 8)])
     assert why is None and sum(e[1]["hbm_bytes_per_launch"] for e in ent) == pytest.approx(2 ** 33)
+
+
+PRODUCT = ("void ntt::(anonymous namespace)::product_kernel<ntt::PassCfg<ntt::FieldGL, 12, 0, true, true, 9, 3, 9, false>, "
+           "ntt::PassCfg<ntt::FieldGL, 12, 0, true, false, 9, 3, 9, false> >(ntt::PassArgs<ntt::PassCfg<ntt::FieldGL, 12, 0, true, true, 9, 3, 9, false> >, "
+           "ntt::PassCfg<ntt::FieldGL, 12, 0, true, true, 9, 3, 9, false>::W const*, ntt::PassArgs<ntt::PassCfg<ntt::FieldGL, 12, 0, true, false, 9, 3, 9, false> >)")
+
+
+def test_config_summary_per_operation(tmp_path):
+    """tools/config_summary.py (configs 2 and 4 under the headline's evidence standard): the product's kernels -- fused middle
+    pass, inverse column pass twice per operation (once per operand), forward column pass once -- reduce to HBM bytes and VALU
+    instructions PER OPERATION; the product kernel is recognised (kernel_key.parse_kernel) and charged three 12-stage networks."""
+    import config_summary as CS
+    from configs import CONFIGS, algorithmic_bytes, butterflies
+    from kernel_key import parse_kernel
+
+    pk = parse_kernel(PRODUCT)
+    assert pk["kind"] == "product" and pk["log_m"] == 12 and pk["short"] == "product_12" and pk["stage_legs"] == 3
+    assert parse_kernel(kname_sc(8, 4, False, True, 4, False))["kind"] == "pass" and parse_kernel(OTHER) is None
+    c = CONFIGS["cfg4"]
+    n, batch = 1 << 20, 512
+    assert algorithmic_bytes(c) == 9 * n * 8 * batch and butterflies(c) == 3 * batch * (n // 2) * 20
+    inv_col, fwd_col = kname_sc(8, 12, False, True, 4, False), kname_sc(8, 12, False, False, 4, False)
+    ops = 4
+    word_kib = n * 8 * batch / 1024.0  # one pass over one operand, in KiB
+    fr, wr, sq = [], [], []
+    for op in range(ops):
+        for name, launches, rd, wrt, ipb, stages, legs in ((inv_col, 2, 1, 1, 21.4, 8, 1), (PRODUCT, 1, 2, 1, 24.0, 12, 3), (fwd_col, 1, 1, 1, 22.2, 8, 1)):
+            for l in range(launches):
+                t0 = 1000 * (op * 10 + l)
+                fr.append((name, 1 << 24, "FETCH_SIZE", rd * word_kib / 2, t0, t0 + 900))   # the counter sees half of the bytes read
+                wr.append((name, 1 << 24, "WRITE_SIZE", wrt * word_kib, t0, t0 + 900))
+                wave_bf = legs * batch * (n // 2) * stages / 64.0
+                sq.append((name, 1 << 24, "SQ_INSTS_VALU", ipb * wave_bf, t0, t0 + 900))
+                sq.append((name, 1 << 24, "GRBM_GUI_ACTIVE", 8 * 3.0e6, t0, t0 + 900))
+                sq.append((name, 1 << 24, "SQ_WAVE_CYCLES", 3.0e9, t0, t0 + 900))
+    fr.append((OTHER, 1 << 24, "FETCH_SIZE", 1e9, 1, 2))
+    pf, pw, ps = tmp_path / "f.csv", tmp_path / "w.csv", tmp_path / "s.csv"
+    write_csv(pf, fr)
+    write_csv(pw, wr)
+    write_csv(ps, sq)
+    t = CS.summarize_pmc("cfg4", ops, str(pf), str(pw), src_hash="abc")
+    assert len(t["kernels"]) == 3 and t["src_hash"] == "abc" and t["config"] == "cfg4"
+    by = {v["short"]: v for v in t["kernels"].values()}
+    assert by["pass_col_8_inv"]["launches_per_op"] == 2 and by["product_12"]["launches_per_op"] == 1
+    # inverse column passes 2 x 2N, fused middle 3N, forward column 2N = the 9N words the product is priced on
+    assert t["per_op"]["hbm_bytes"] == pytest.approx(9 * n * 8 * batch) and t["per_op"]["ratio_to_algorithmic"] == pytest.approx(1.0)
+    s = CS.summarize_sq("cfg4", ops, str(ps), src_hash="abc")
+    bs = {v["short"]: v for v in s["kernels"].values()}
+    assert bs["pass_col_8_inv"]["valu_instr_per_butterfly"] == pytest.approx(21.4)
+    assert bs["product_12"]["valu_instr_per_butterfly"] == pytest.approx(24.0)
+    assert bs["pass_col_8_fwd"]["valu_instr_per_butterfly"] == pytest.approx(22.2)
+    assert bs["product_12"]["kernel_cycles"] == pytest.approx(3.0e6) and bs["product_12"]["held_clock_GHz"] == pytest.approx(3.0e6 / 900)
+    # per operation: 60 stage-networks of N/2 butterflies per polynomial... 2x8 inverse + 3x12 middle + 8 forward = 60 = 3 x 20 stages
+    assert s["per_op"]["butterflies_in_profiled_kernels"] == pytest.approx(butterflies(c))
+    want = (21.4 * 16 + 24.0 * 36 + 22.2 * 8) / 60
+    assert s["per_op"]["valu_instr_per_butterfly"] == pytest.approx(want)
+    assert s["per_op"]["kernel_cycles"] == pytest.approx(4 * 3.0e6)  # four launches per operation
+    # a single-pass forward configuration: one kernel, one launch per operation
+    c2 = CONFIGS["cfg2"]
+    k2 = "void ntt::(anonymous namespace)::pass_kernel<ntt::PassCfg<ntt::FieldM32, 12, 0, true, false, 15, 4, 8, true>, false>(x)"
+    rows = [(k2, 1 << 18, "SQ_INSTS_VALU", 12.0 * c2["batch"] * 2048 * 12 / 64, 0, 14000), (k2, 1 << 18, "GRBM_GUI_ACTIVE", 8 * 30000.0, 0, 14000),
+            (k2, 256, "SQ_INSTS_VALU", 5.0, 0, 10)]  # ... and a parity-sized launch of the same kernel: dropped
+    write_csv(ps, rows)
+    s2 = CS.summarize_sq("cfg2", 1, str(ps), src_hash="abc")
+    (e,) = s2["kernels"].values()
+    assert e["launches"] == 1 and e["valu_instr_per_butterfly"] == pytest.approx(12.0) and e["held_clock_GHz"] == pytest.approx(30000.0 / 14000)

@@ -46,6 +46,25 @@ def parse_pass_kernel(name: str):
     return out
 
 
+def parse_kernel(name: str):
+    """parse_pass_kernel() for pass_kernel<...>, and the product's fused middle pass
+    product_kernel<PassCfg<inverse ...>, PassCfg<forward ...>>: key "product PassCfg<...>" (the inverse leg's argument list),
+    short product_<LOG_M>, kind "product".  `stage_legs` = how many LOG_M-stage networks one launch runs per polynomial
+    (1 for a pass; 3 for the product: inverse of a, inverse of b, forward of the product).  None for any other kernel."""
+    if "product_kernel<" in name and "PassCfg<" in name:
+        args = [a.strip() for a in name.split("PassCfg<", 1)[1].split(">", 1)[0].split(",")]
+        if len(args) < 5:
+            return None
+        d = dict(zip(FIELDS, args))
+        return {"cfg": "PassCfg<%s>" % ", ".join(args), "field": d["field"].split("::")[-1], "log_m": int(d["log_m"]),
+                "log_c": int(d["log_c"]), "contig": True, "inv": False, "sc": False, "kind": "product", "stage_legs": 3,
+                "key": "product PassCfg<%s>" % ", ".join(args), "short": "product_%d" % int(d["log_m"])}
+    pk = parse_pass_kernel(name)
+    if pk is not None:
+        pk["kind"], pk["stage_legs"] = "pass", 1
+    return pk
+
+
 def forward_entry(kernels: dict, contig: bool, log_m: int, field: str = "FieldGL"):
     """The ONE forward-direction entry of a summary's `kernels` table for this pass shape, or (None, reason).
     bench.py quotes a counter only through this function: an inverse kernel can never be returned."""
