@@ -97,6 +97,7 @@ struct ntt_plan {
     uint32_t target_wgs;      // workgroups per launch the batch loop of a CONTIG pass is sized for
     uint32_t target_wgs_col;  // ... of a column pass (shorter loops win there)
     int dbg;            // experiment build only (NTT_DEBUG_FLAGS); always 0 in the product
+    int force_variant;  // experiment build only (NTT_PASS_VARIANT=k): every CONTIG pass runs kernel variant k; -1 in the product
     int only_pass;      // experiment build only (NTT_ONLY_PASS=k): ntt_forward launches pass k alone (power / clock of one kernel); -1 in the product
     int fused;          // experiment build only (NTT_FUSED=1): N = 2^16 Goldilocks forward through the XCD-local fused launch
     void *d_fused_ctl;  // counters of the fused launch (plan-owned; null in the product)
@@ -171,6 +172,10 @@ ntt::ErasedArgs base_args(const ntt_plan *pl, const PassDesc &pd, const void *in
     a.batch = (uint32_t) batch;
     a.target_wgs = pd.contig ? pl->target_wgs : pl->target_wgs_col;
     a.dbg = pl->dbg;
+    a.variant = pd.variant;
+#if defined(NTT_EXPERIMENT)
+    if (pl->force_variant >= 0 && pd.contig) a.variant = pl->force_variant;  // NTT_PASS_VARIANT=k: A/B of a kernel variant
+#endif
     return a;
 }
 
@@ -325,6 +330,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     pl->target_wgs_col = 2 * pl->target_wgs;
     pl->dbg = 0;
     pl->only_pass = -1;
+    pl->force_variant = -1;
     pl->fused = 0;
     pl->fused_max_batch = 0;
     pl->alts = plan_alternatives(logn, word_bytes, p);
@@ -343,6 +349,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
     }
     if (const char *e = getenv("NTT_DEBUG_FLAGS")) pl->dbg = atoi(e);
     if (const char *e = getenv("NTT_ONLY_PASS")) pl->only_pass = atoi(e);
+    if (const char *e = getenv("NTT_PASS_VARIANT")) pl->force_variant = atoi(e);
     if (const char *e = getenv("NTT_FUSED")) pl->fused = atoi(e);
     if (const char *e = getenv("NTT_PLAN_SPLIT")) {  // "8,6,6" = CONTIG 8 stages + two 6-stage column passes
         std::vector<PassDesc> v;
@@ -354,7 +361,7 @@ int ntt_plan_create(ntt_plan_t *out, int logn, uint64_t p, int word_bytes, int d
             if (end == c) break;
             if (v.empty()) ok = m >= 1 && m <= (word_bytes == 4 ? 14 : 13);
             else ok = m >= MIN_COL_LOG_M && m <= MAX_COL_LOG_M_WIDE;
-            v.push_back({v.empty(), s0, (int) m});
+            v.push_back({v.empty(), s0, (int) m, 0});
             s0 += (int) m;
             c = *end == ',' ? end + 1 : end;
         }
@@ -531,6 +538,11 @@ int64_t ntt_plan_info(ntt_plan_t pl, int what) NTT_GUARD {
         if (k >= 1 && k <= 7) return k - 1 < (int) alt.passes.size() ? alt.passes[(size_t) k - 1].log_m : NTT_E_ARG;
         if (k >= 8 && k <= 14) return k - 8 < (int) alt.passes.size() ? alt.passes[(size_t) k - 8].s0 : NTT_E_ARG;
         return (int64_t) alt.min_batch;  // k == 15
+    }
+    if (what >= 512 && what < 512 + 16 * (int) pl->alts.size()) {  // kernel variant of pass k of alternative a (PassDesc::variant)
+        const PlanAlt &alt = pl->alts[(size_t) (what - 512) / 16];
+        const int k = (what - 512) % 16;
+        return k < (int) alt.passes.size() ? alt.passes[(size_t) k].variant : NTT_E_ARG;
     }
     if (what >= 32 && what < 32 + (int) pl->passes.size()) return pl->passes[what - 32].log_m;
     if (what >= 64 && what < 64 + (int) pl->passes.size()) return pl->passes[what - 64].s0;

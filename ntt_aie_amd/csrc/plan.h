@@ -20,6 +20,7 @@ struct PassDesc {
     bool contig;
     int s0;
     int log_m;
+    int variant = 0;  // which kernel of this (contig, log_m) runs: 0 = default; 1 = wide radix-8 (4-byte CONTIG 10..12 stages, 512 threads)
 };
 
 inline uint64_t mulmod(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t) (((u128) a * b) % p); }
@@ -140,6 +141,18 @@ inline bool m32_lazy_modulus(uint64_t p) { return p < 0x40000000ull; }
 #define NTT_ALT_MIN_BATCH_M32_14 128  // 4-byte lazy primes, N = 2^14: one 14-stage pass (one 1024-thread workgroup per CU)
 #endif
 
+// measured crossover of the wide variant (same process, interleaved, outputs compared: profiles/r04_ab_m32_wide.txt; wide against
+// radix-16, forward / inverse):
+//   p >= 2^31 (carry-select butterflies), N = 2^12: batch 1 -11 / -11 %, 64 -18 / -13 %, 256 -18 / -13 %, 1024 -6 / 0 %, 4096 +3 / +12 %,
+//     65536 +3 / +5 %; N = 2^11: 1 .. 256 -5 .. -6 / -12 .. -18 %, 1024 -1 / -9 %, 4096 +4 / +4 %; N = 2^10: 1 .. 1024 -4 .. -6 / -8 .. -12 %
+//   p < 2^31 (v_min corrections) and p < 2^30 (lazy): -1 .. -6 % up to batch 256, even or +3 % at 1024, +3 .. +19 % from 4096 on
+#ifndef NTT_ALT_MIN_BATCH_M32_WIDE
+#define NTT_ALT_MIN_BATCH_M32_WIDE 2048      // 4-byte N = 2^10 .. 2^12, p >= 2^31: the default radix-16 kernel from this batch on
+#endif
+#ifndef NTT_ALT_MIN_BATCH_M32_WIDE_LIGHT
+#define NTT_ALT_MIN_BATCH_M32_WIDE_LIGHT 512  // ... p < 2^31 (9 / 11-instruction butterflies: the wide variant's extra exchange weighs more)
+#endif
+
 inline std::vector<PlanAlt> plan_alternatives(int n, int word_bytes, uint64_t p) {
     std::vector<PlanAlt> alts;
     std::vector<PassDesc> def = plan_passes(n, word_bytes);
@@ -152,6 +165,19 @@ inline std::vector<PlanAlt> plan_alternatives(int n, int word_bytes, uint64_t p)
         // +4 .. +6 % inverse at batches 8 .. 32 and even from 64 on; the heavier 4-byte streams (p >= 2^30) gain only for one or two
         // polynomials (-7 .. -14 %) and lose +5 .. +16 % from batch 8 on (their 13-stage pass is VALU-bound): three light passes there
         alts.push_back({{{true, 0, 8}, {false, 8, 7}, {false, 15, 7}}, 3});
+    }
+    if (word_bytes == 4 && n >= 10 && n <= 12) {
+        // Single-pass 4-byte sizes 2^10 .. 2^12 (BASELINE config 2 is N = 2^12, batch 1024): below the batch that fills the SIMDs
+        // the same unit runs on 512 threads x 8 words (variant 1: radix-8 rounds, one more LDS exchange) -- twice the waves per
+        // polynomial, so a launch of one generation of workgroups issues its butterflies at 2 .. 6 waves per SIMD instead of
+        // 1 .. 4 (VOP3 forms issue in 3.4 cycles per wave-instruction at 4 waves per SIMD, 2.0 at 8: profiles/r04_valu_issue_cost.json).
+        // Same-process crossover (tools/run_ab_m32_wide_r04.sh -> profiles/r04_ab_m32_wide.txt).  Alternative 0 = the wide variant,
+        // alternative 1 = the default radix-16 kernel from the threshold on; same stages, same words.
+        std::vector<PassDesc> wide = def;
+        wide[0].variant = 1;
+        alts.clear();
+        alts.push_back({wide, 0});
+        alts.push_back({def, p < 0x80000000ull ? (uint64_t) NTT_ALT_MIN_BATCH_M32_WIDE_LIGHT : (uint64_t) NTT_ALT_MIN_BATCH_M32_WIDE});
     }
     if (word_bytes == 8 && n == 13) alts.push_back({{{true, 0, 13}}, NTT_ALT_MIN_BATCH_GL13});
     if (word_bytes == 4 && m32_lazy_modulus(p) && n == 14) alts.push_back({{{true, 0, 14}}, NTT_ALT_MIN_BATCH_M32_14});

@@ -125,6 +125,13 @@ class NTTPlan:
                         int(L.ntt_plan_info(self._h, 256 + 16 * a + 15))))
         return out
 
+    @property
+    def alternative_variants(self) -> list[list[int]]:
+        """[kernel variant per pass] of every alternative (ntt_plan_info 512+: 0 = the default kernel of the pass shape)."""
+        L = _lib.lib()
+        return [[int(L.ntt_plan_info(self._h, 512 + 16 * a + i)) for i in range(len(stages))]
+                for a, (stages, _) in enumerate(self.alternatives)]
+
     def set_policy(self, alternative: int) -> None:
         """-1 (default): the launcher picks the decomposition by batch; k >= 0: always alternative k (ntt_plan_set_policy)."""
         check(_lib.lib().ntt_plan_set_policy(self._h, alternative), "ntt_plan_set_policy")

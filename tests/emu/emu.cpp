@@ -149,6 +149,7 @@ struct Erased {
     uint32_t target_wgs;
     const void *in2;
     uint64_t pw_scale;
+    int variant;  // PassDesc::variant of the pass being run (pass_kernel.inc: 1 = 4-byte CONTIG 10..12 stages on 512 threads x 8 words)
 };
 
 template <class F>
@@ -297,6 +298,14 @@ int dispatch(bool contig, int log_m, const Erased &e) {
             if constexpr (sizeof(typename F::W) == 4) return run_cfg<PassCfg<F, 14, 0, true, INV, 0xF, 4, 10>>(e);
             else return -1;
         }
+        if constexpr (sizeof(typename F::W) == 4) {
+            // pass_kernel.inc: the wide radix-8 variant of the 4-byte CONTIG passes (same conditions as there)
+            if (e.variant == 1 && e.in2 == nullptr && !(e.layout == LAYOUT_AIE_BLOCK16 && e.s0 + log_m == e.n)) {
+                if (log_m == 10) return run_cfg<PassCfg<F, 10, 0, true, INV, 0xF, 3, 9>>(e);
+                if (log_m == 11) return run_cfg<PassCfg<F, 11, 0, true, INV, 0xF, 3, 9>>(e);
+                if (log_m == 12) return run_cfg<PassCfg<F, 12, 0, true, INV, 0xF, 3, 9>>(e);
+            }
+        }
         if (contig_log_e(log_m, sizeof(typename F::W), e.s0 + log_m == e.n) == 3) {
             if constexpr (!INV) {
                 if (e.in2 != nullptr) {  // fused product: the non-DMA twins (pass_kernel.inc)
@@ -334,7 +343,7 @@ extern "C" {
 // Forward (inverse = 0) or exact inverse (inverse = 1, scaled by N^-1 when scale != 0)
 // of `batch` polynomials, host buffers, table T in plain form (N words).
 // passes_override: 0 = planner's split; otherwise a list "first,col,col,.." packed
-// 4 bits each from the low nibble (used to exercise every tile shape).
+// 4 bits each from the low nibble (used to exercise every tile shape); bits 60..63 = PassDesc::variant of the CONTIG pass.
 int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, const void *in, void *out,
                   uint32_t batch, int inverse, int layout, int scale, uint32_t target_wgs,
                   uint64_t passes_override) {
@@ -363,6 +372,8 @@ int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, con
         for (size_t i = 0; i < N / 2; i++) tsc[i] = to_table_form(mulmod(Ti[N / 2 + i], ninv, p), p, 8);
     }
     std::vector<PassDesc> passes;
+    const int contig_variant = (int) (passes_override >> 60);
+    passes_override &= (1ull << 60) - 1;
     if (passes_override == 0) {
         passes = plan_passes(logn, word_bytes);
     } else {
@@ -403,6 +414,7 @@ int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, con
         e.in = cur;
         e.out = out;
         e.s0 = passes[i].s0;
+        e.variant = passes[i].contig ? (contig_variant ? contig_variant : passes[i].variant) : 0;
         e.do_scale = (inverse && scale && i == 0) ? 1 : 0;
         int rc;
         if (m64)
@@ -560,6 +572,12 @@ int emu_plan_alt(int logn, int word_bytes, uint64_t p, int alt, int *out_triples
         out_triples[3 * i + 2] = v[i].log_m;
     }
     return (int) v.size();
+}
+// kernel variant (PassDesc::variant) of pass `pass` of alternative `alt`, or -1
+int emu_plan_alt_variant(int logn, int word_bytes, uint64_t p, int alt, int pass) {
+    auto alts = plan_alternatives(logn, word_bytes, p);
+    if (alt < 0 || alt >= (int) alts.size() || pass < 0 || pass >= (int) alts[(size_t) alt].passes.size()) return -1;
+    return alts[(size_t) alt].passes[(size_t) pass].variant;
 }
 int emu_select_alt(int logn, int word_bytes, uint64_t p, uint64_t batch) {
     return select_alternative(plan_alternatives(logn, word_bytes, p), batch);

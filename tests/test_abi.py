@@ -137,7 +137,7 @@ def test_product_library_reads_no_environment_and_has_no_experiment_paths(hiplib
     exist only in the -DNTT_EXPERIMENT build that tools/ load; the product .so must not even contain their names,
     and the experimental fused launch must not be linked into it."""
     blob = open(os.path.join(ROOT, "ntt_aie_amd", "libntt_hip.so"), "rb").read()
-    for name in (b"NTT_DEBUG_FLAGS", b"NTT_FUSED", b"NTT_PLAN_SPLIT", b"NTT_TARGET_WGS", b"NTT_ONLY_PASS", b"fused_gl16"):
+    for name in (b"NTT_DEBUG_FLAGS", b"NTT_FUSED", b"NTT_PLAN_SPLIT", b"NTT_TARGET_WGS", b"NTT_ONLY_PASS", b"NTT_PASS_VARIANT", b"fused_gl16"):
         assert name not in blob, name
     assert not os.path.exists(os.path.join(ROOT, "ntt_aie_amd", "csrc", "fused_gl16.hip"))
 

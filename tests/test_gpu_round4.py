@@ -283,3 +283,68 @@ def test_bench_json_contract_frac_step_and_gpu_input_sample():
     assert c["sample_is_gpu_input"] is True and "GPU's own input" in c["sample"] and c["kind"] == "port" and c["sample_rows"] >= 16
     assert d["all_ranks_verified"] is True and d["world_size_seen"] == 1 and d["ranks"][0]["rank"] == 0
     assert d["launch"] == "process-per-gpu" and "r02_power_probe" not in r["bound_note"]
+
+
+# ---- the wide radix-8 variant of the 4-byte single-pass sizes (plan.h: PassDesc::variant 1) ---------------------------------
+def _check_all_legs(eng, oracle, pl, T, p, dt, batches, seed):
+    n = pl.n
+    for batch in batches:
+        a = _rand(batch, n, p, dt, seed + batch)
+        want = oracle.ntt(a, T, p, nthreads=8)
+        d = eng.to_device(a, "cuda:0")
+        f = pl.forward(d)
+        assert np.array_equal(eng.to_host(f), want), ("forward", batch)
+        blk = pl.forward(d, layout=eng.LAYOUT_AIE_BLOCK16)
+        assert np.array_equal(eng.to_host(blk), oracle.block16(want)), ("block16", batch)
+        assert np.array_equal(eng.to_host(pl.inverse(blk, layout=eng.LAYOUT_AIE_BLOCK16)), a), ("inverse of block16", batch)
+        assert np.array_equal(eng.to_host(pl.inverse(f)), a), ("inverse", batch)
+        u = eng.to_host(pl.inverse(f, scale=False)).astype(object)
+        assert np.array_equal((u % p).astype(dt), ((a.astype(object) * n) % p).astype(dt)) and int(u.max()) < p, ("unscaled inverse", batch)
+        g = d.clone()
+        pl.forward(g, g)
+        pl.inverse(g, g)
+        assert np.array_equal(eng.to_host(g), a), ("in place round trip", batch)
+
+
+@pytest.mark.parametrize("p,g", [(3221225473, 5), (2013265921, 31), (998244353, 3), (3329, 3)])
+def test_wide_variant_of_4byte_single_pass_sizes(eng, oracle, p, g):
+    """4-byte N = 2^10 .. 2^12: alternative 0 runs the unit on 512 threads x 8 words (variant 1) below a batch threshold,
+    alternative 1 the default radix-16 kernel from it on.  Both pinned and through the batch rule: forward, both layouts (the
+    AIE_BLOCK16 legs keep the default kernel), inverse, unscaled inverse, in place, ragged batches, every modulus class; the
+    negacyclic product under both (its fused kernel is its own)."""
+    from ntt_aie_amd import _lib
+
+    L = _lib.lib()
+    dt = np.uint32
+    for logn in (10, 11, 12):
+        n = 1 << logn
+        T = oracle.make_roots(n, p, g, 4)
+        pl = eng.NTTPlan(logn, p, 4, 0)
+        pl.set_twiddles(T)
+        alts = pl.alternatives
+        assert [a[0] for a in alts] == [[logn], [logn]] and alts[0][1] == 0 and alts[1][1] >= 256
+        assert pl.alternative_variants == [[1], [0]]
+        thr = alts[1][1]
+        assert int(L.ntt_plan_select(pl._h, thr - 1)) == 0 and int(L.ntt_plan_select(pl._h, thr)) == 1
+        for k in (0, 1):
+            pl.set_policy(k)
+            _check_all_legs(eng, oracle, pl, T, p, dt, (1, 3, 37, 300), seed=logn * 10 + k)
+        pl.set_policy(-1)
+        for batch in (thr - 1, thr):
+            a = _rand(batch, n, p, dt, batch)
+            f = pl.forward(eng.to_device(a, "cuda:0"))
+            rows = [0, 1, batch // 2, batch - 1]
+            assert np.array_equal(eng.to_host(f)[rows], oracle.ntt(a[rows], T, p, nthreads=4)), batch
+            assert np.array_equal(eng.to_host(pl.inverse(f)), a), batch
+    if (p - 1) % (1 << 13) == 0:  # a negacyclic table exists: the product under both alternatives
+        logn, n = 12, 4096
+        pl = eng.NTTPlan(logn, p, 4, 0)
+        T2 = pl.make_table(2, g)
+        pl.set_twiddles(T2)
+        a, b = _rand(5, n, p, dt, 1), _rand(5, n, p, dt, 2)
+        A, B = oracle.intt(a, T2, p), oracle.intt(b, T2, p)
+        want = oracle.ntt(oracle.pointwise(A, B, p, n % p), T2, p)
+        for k in (0, 1):
+            pl.set_policy(k)
+            c = pl.polymul_negacyclic(eng.to_device(a, "cuda:0"), eng.to_device(b, "cuda:0"))
+            assert np.array_equal(eng.to_host(c), want), k
