@@ -603,7 +603,7 @@ def run_single_process(args):
     ends when the slowest device does.  NTT_BENCH_ONE_DEVICE=1 places every clone on device 0 (rehearsal on a one-GPU box)."""
     import torch
 
-    from ntt_aie_amd.plan import NTTPlan
+    from ntt_aie_amd.multi import MultiDevicePlan
 
     ndev = args.gpus
     if not torch.cuda.is_available():
@@ -616,17 +616,15 @@ def run_single_process(args):
         return 2
     devs = [0] * ndev if rehearsal else list(range(ndev))
     logn, n, batch, p = args.logn, 1 << args.logn, args.batch, GOLDILOCKS
-    plan0 = NTTPlan(logn, p, 8, devs[0])
-    table = plan0.make_roots(7)
-    plan0.set_twiddles(table)
-    plans = [plan0] + [plan0.clone(d) for d in devs[1:]]  # hipMemcpyPeer of the tables when the device differs
-    xs, ys, streams = [], [], []
+    mdp = MultiDevicePlan(logn, p, 8, devs)  # one plan on the first device ...
+    table = mdp.make_table(0, 7)
+    mdp.set_twiddles(table)                  # ... ntt_plan_clone onto the others: hipMemcpyPeer of the tables when the device differs
+    plans, streams, plan0 = mdp.plans, mdp.streams, mdp.plans[0]
+    xs, ys = [], []
     for i, d in enumerate(devs):
         with torch.cuda.device(d):
-            dev = torch.device("cuda", d)
-            xs.append(synth_batch(torch, batch, n, dev, first_row=i * batch))  # shard i = rows [i*batch, (i+1)*batch) of the job
+            xs.append(synth_batch(torch, batch, n, torch.device("cuda", d), first_row=i * batch))  # shard i = rows [i*batch, (i+1)*batch) of the job
             ys.append(torch.empty_like(xs[-1]))
-            streams.append(torch.cuda.Stream(device=dev))
 
     def step():
         for pl, x, y, st in zip(plans, xs, ys, streams):

@@ -123,8 +123,8 @@ int ntt_plan_get_twiddles(ntt_plan_t plan, int inverse, void *host_T);
  * 8 the largest number of passes over all alternatives (capacity for ntt_forward_profile),
  * 256 + 16*a + k for alternative a: k = 0 number of passes, k = 1..7 stages in pass k-1,
  * k = 8..14 first stage of pass k-8, k = 15 the smallest batch this alternative is chosen for;
- * 512 + 16*a + k: the kernel variant of pass k of alternative a (0 = the default kernel of that pass shape; 1 = a 4-byte CONTIG
- * pass of 10..12 stages on twice the threads, for launches too small to fill the device) */
+ * 512 + 16*a + k: the kernel variant of pass k of alternative a (0 = the default kernel of that pass shape; 1 = a single-pass
+ * size of 2^10..2^12 words on twice the threads, chosen below the batch that fills the device) */
 int64_t ntt_plan_info(ntt_plan_t plan, int what);
 
 /* The stage decomposition into HBM passes is chosen at LAUNCH, by batch size, among alternatives fixed at plan creation

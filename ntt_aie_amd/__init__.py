@@ -4,7 +4,7 @@ reference's (input, root, output) buffer contract (hal-lab-u-tokyo/ntt-aie,
 src/test.cpp:115-190, src/aie2.py:320-337)."""
 from ._lib import (LAYOUT_AIE_BLOCK16, LAYOUT_NATURAL, LIB_PATH, NTTError)  # noqa: F401
 
-__all__ = ["NTTPlan", "NTTError", "LAYOUT_NATURAL", "LAYOUT_AIE_BLOCK16", "GOLDILOCKS", "to_device",
+__all__ = ["NTTPlan", "MultiDevicePlan", "NTTError", "LAYOUT_NATURAL", "LAYOUT_AIE_BLOCK16", "GOLDILOCKS", "to_device",
            "to_host", "version"]
 
 
@@ -17,4 +17,7 @@ def __getattr__(name):
     if name in ("NTTPlan", "GOLDILOCKS", "to_device", "to_host"):
         from . import plan
         return getattr(plan, name)
+    if name == "MultiDevicePlan":
+        from . import multi
+        return multi.MultiDevicePlan
     raise AttributeError(name)

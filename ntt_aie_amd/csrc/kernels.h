@@ -26,7 +26,7 @@ struct ErasedArgs {
     const void *in2;     // forward CONTIG pass: second operand of a fused pointwise product (or null)
     uint64_t pw_scale;   // scale * R^2 (see PassArgs::pw_scale)
     const void *skip_if;  // experiment build only: device word, non-zero = the launch is a no-op (fallback behind the fused kernel)
-    int variant;          // PassDesc::variant (plan.h): 0 = the default kernel of this (contig, log_m); 1 = 4-byte CONTIG pass of 10..12
+    int variant;          // PassDesc::variant (plan.h): 0 = the default kernel of this (contig, log_m); 1 = single-pass CONTIG unit of 10..12
                           // stages as radix-8 rounds in 512 threads (twice the waves per unit: small batches, one generation of workgroups)
 };
 

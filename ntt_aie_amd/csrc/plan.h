@@ -20,7 +20,7 @@ struct PassDesc {
     bool contig;
     int s0;
     int log_m;
-    int variant = 0;  // which kernel of this (contig, log_m) runs: 0 = default; 1 = wide radix-8 (4-byte CONTIG 10..12 stages, 512 threads)
+    int variant = 0;  // which kernel of this (contig, log_m) runs: 0 = default; 1 = wide radix-8 (single-pass CONTIG of 10..12 stages, 512 threads x 8 words)
 };
 
 inline uint64_t mulmod(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t) (((u128) a * b) % p); }
@@ -149,6 +149,11 @@ inline bool m32_lazy_modulus(uint64_t p) { return p < 0x40000000ull; }
 #ifndef NTT_ALT_MIN_BATCH_M32_WIDE
 #define NTT_ALT_MIN_BATCH_M32_WIDE 2048      // 4-byte N = 2^10 .. 2^12, p >= 2^31: the default radix-16 kernel from this batch on
 #endif
+//   8-byte words (Goldilocks; profiles/r04_ab_gl_wide.txt), N = 2^12: batch 1 -17 / -19 %, 64 -15 / -16 %, 256 -14 / -15 %, 1024 -3 / -1 %,
+//     4096 +5 / +6 %, 16384 +6 / +11 %; N = 2^11: 1 .. 256 -12 .. -17 %, 1024 -7 / -7 %, 4096 +4 / -8 %; N = 2^10: 1 .. 1024 -8 .. -16 %, 4096 +4 / -10 %
+#ifndef NTT_ALT_MIN_BATCH_W8_WIDE
+#define NTT_ALT_MIN_BATCH_W8_WIDE 2048       // 8-byte N = 2^10 .. 2^12: the default radix-16 kernel from this batch on
+#endif
 #ifndef NTT_ALT_MIN_BATCH_M32_WIDE_LIGHT
 #define NTT_ALT_MIN_BATCH_M32_WIDE_LIGHT 512  // ... p < 2^31 (9 / 11-instruction butterflies: the wide variant's extra exchange weighs more)
 #endif
@@ -166,8 +171,8 @@ inline std::vector<PlanAlt> plan_alternatives(int n, int word_bytes, uint64_t p)
         // polynomials (-7 .. -14 %) and lose +5 .. +16 % from batch 8 on (their 13-stage pass is VALU-bound): three light passes there
         alts.push_back({{{true, 0, 8}, {false, 8, 7}, {false, 15, 7}}, 3});
     }
-    if (word_bytes == 4 && n >= 10 && n <= 12) {
-        // Single-pass 4-byte sizes 2^10 .. 2^12 (BASELINE config 2 is N = 2^12, batch 1024): below the batch that fills the SIMDs
+    if (n >= 10 && n <= 12) {
+        // Single-pass sizes 2^10 .. 2^12, both word widths (BASELINE config 2 is 4-byte N = 2^12, batch 1024): below the batch that fills the SIMDs
         // the same unit runs on 512 threads x 8 words (variant 1: radix-8 rounds, one more LDS exchange) -- twice the waves per
         // polynomial, so a launch of one generation of workgroups issues its butterflies at 2 .. 6 waves per SIMD instead of
         // 1 .. 4 (VOP3 forms issue in 3.4 cycles per wave-instruction at 4 waves per SIMD, 2.0 at 8: profiles/r04_valu_issue_cost.json).
@@ -177,7 +182,8 @@ inline std::vector<PlanAlt> plan_alternatives(int n, int word_bytes, uint64_t p)
         wide[0].variant = 1;
         alts.clear();
         alts.push_back({wide, 0});
-        alts.push_back({def, p < 0x80000000ull ? (uint64_t) NTT_ALT_MIN_BATCH_M32_WIDE_LIGHT : (uint64_t) NTT_ALT_MIN_BATCH_M32_WIDE});
+        alts.push_back({def, word_bytes == 8 ? (uint64_t) NTT_ALT_MIN_BATCH_W8_WIDE
+                             : p < 0x80000000ull ? (uint64_t) NTT_ALT_MIN_BATCH_M32_WIDE_LIGHT : (uint64_t) NTT_ALT_MIN_BATCH_M32_WIDE});
     }
     if (word_bytes == 8 && n == 13) alts.push_back({{{true, 0, 13}}, NTT_ALT_MIN_BATCH_GL13});
     if (word_bytes == 4 && m32_lazy_modulus(p) && n == 14) alts.push_back({{{true, 0, 14}}, NTT_ALT_MIN_BATCH_M32_14});

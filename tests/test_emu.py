@@ -121,15 +121,15 @@ def test_plan_alternatives():
     # N = 2^22: two trips (13 + 9) for Goldilocks and the lazy 4-byte primes; the heavier 4-byte streams take three light passes from batch 3 on
     assert [x[0] for x in alts(22, 8, GOLD)] == [[13, 9]] == [x[0] for x in alts(22, 4, 3329)]
     assert alts(22, 4, 3221225473) == [([13, 9], 0), ([8, 7, 7], 3)] == alts(22, 4, 2013265921)
-    # round 4: 4-byte single-pass sizes 2^10 .. 2^12 -- the same one pass as two KERNEL variants: 512 threads x 8 words (variant 1)
-    # below the batch that fills the device, the default 256 x 16 from it on; no other size or word width has a variant
-    for p4 in (3221225473, 998244353):
+    # round 4: single-pass sizes 2^10 .. 2^12 -- the same one pass as two KERNEL variants: 512 threads x 8 words (variant 1)
+    # below the batch that fills the device, the default 256 x 16 from it on; no other size has a variant
+    for wb4, p4 in ((4, 3221225473), (4, 998244353), (8, GOLD), (8, 0x3FFFFFEE00000001)):
         for logn in (10, 11, 12):
-            a = alts(logn, 4, p4)
+            a = alts(logn, wb4, p4)
             assert [x[0] for x in a] == [[logn], [logn]] and a[0][1] == 0 and a[1][1] >= 256
-            assert [L.emu_plan_alt_variant(logn, 4, p4, k, 0) for k in (0, 1)] == [1, 0]
+            assert [L.emu_plan_alt_variant(logn, wb4, p4, k, 0) for k in (0, 1)] == [1, 0]
     assert alts(12, 4, 998244353)[1][1] <= alts(12, 4, 3221225473)[1][1]  # the lazy class hands over to radix-16 earlier
-    for wb, p0, logn in ((4, 3221225473, 9), (4, 3221225473, 13), (8, GOLD, 12), (8, GOLD, 13), (4, 3221225473, 16)):
+    for wb, p0, logn in ((4, 3221225473, 9), (4, 3221225473, 13), (8, GOLD, 9), (8, GOLD, 13), (4, 3221225473, 16), (8, GOLD, 16)):
         assert all(L.emu_plan_alt_variant(logn, wb, p0, k, i) == 0 for k in range(len(alts(logn, wb, p0))) for i in range(len(alts(logn, wb, p0)[k][0])))
 
 
@@ -308,18 +308,20 @@ def test_general_64bit_modulus_every_shape(oracle, p, g):
             _run(oracle, 8, sum(ov), p, g, 2, inverse=inv, scale=inv, tw=4, ov=emu_lib.pack_passes(*ov), seed=11)
 
 
-@pytest.mark.parametrize("wb,p,g", [(4, 3221225473, 5), (4, 2013265921, 31), (4, 998244353, 3), (4, 3329, 3)])
-def test_wide_radix8_variant_of_the_4byte_contig_passes(oracle, wb, p, g):
-    """PassDesc::variant 1 (round 4): a 4-byte unit of 2^10 .. 2^12 words on 512 threads x 8 words -- radix-8 rounds of
-    3 + 3 + 3 + (1..3) stages, four LDS exchanges of which only the last spans waves at 2^12 -- instead of 256 x 16.  Every
-    modulus class (32-bit, 31-bit, lazy), both directions, both layouts, ragged batch and in place, under the LDS hazard
-    tracker; as the first pass of a two-pass plan as well."""
+@pytest.mark.parametrize("wb,p,g", [(4, 3221225473, 5), (4, 2013265921, 31), (4, 998244353, 3), (8, GOLD, 7), (8, 0x3FFFFFEE00000001, 3)])
+def test_wide_radix8_variant_of_the_single_pass_sizes(oracle, wb, p, g):
+    """PassDesc::variant 1 (round 4): a single-pass unit of 2^10 .. 2^12 words on 512 threads x 8 words -- radix-8 rounds of
+    3 + 3 + 3 + (1..3) stages (8-byte forward: the LDS-DMA kernel, here as the LAST pass of a plan) -- instead of 256 x 16.
+    Every 4-byte modulus class (32-bit, 31-bit, lazy), Goldilocks and the general 64-bit modulus, both directions (the scaled
+    inverse folds N^-1 into stage 0 for 8-byte words), both layouts (AIE_BLOCK16 keeps the default kernel), ragged batch and in
+    place, under the LDS hazard tracker; 4-byte: as the first pass of a two-pass plan as well."""
     wide = 1 << 60
     for logn in (10, 11, 12):
         for inv in (0, 1):
-            _run(oracle, wb, logn, p, g, 5, inverse=inv, layout=inv, scale=1, tw=4, ov=wide | emu_lib.pack_passes(logn), seed=logn)
-            _run(oracle, wb, logn, p, g, 1, inverse=inv, layout=1 - inv, scale=1 - inv if inv else 1, tw=2048,
-                 ov=wide | emu_lib.pack_passes(logn), seed=logn + 1, inplace=True)
+            _run(oracle, wb, logn, p, g, 3, inverse=inv, layout=inv, scale=1, tw=4, ov=wide | emu_lib.pack_passes(logn), seed=logn)
+            if logn != 11:  # in place, one polynomial, the other layout / unscaled inverse
+                _run(oracle, wb, logn, p, g, 1, inverse=inv, layout=1 - inv, scale=1 - inv if inv else 1, tw=2048,
+                     ov=wide | emu_lib.pack_passes(logn), seed=logn + 1, inplace=True)
     if p == 3221225473:
         for ov in ((10, 6), (12, 5)):
             for inv in (0, 1):

@@ -306,20 +306,22 @@ def _check_all_legs(eng, oracle, pl, T, p, dt, batches, seed):
         assert np.array_equal(eng.to_host(g), a), ("in place round trip", batch)
 
 
-@pytest.mark.parametrize("p,g", [(3221225473, 5), (2013265921, 31), (998244353, 3), (3329, 3)])
-def test_wide_variant_of_4byte_single_pass_sizes(eng, oracle, p, g):
-    """4-byte N = 2^10 .. 2^12: alternative 0 runs the unit on 512 threads x 8 words (variant 1) below a batch threshold,
-    alternative 1 the default radix-16 kernel from it on.  Both pinned and through the batch rule: forward, both layouts (the
-    AIE_BLOCK16 legs keep the default kernel), inverse, unscaled inverse, in place, ragged batches, every modulus class; the
-    negacyclic product under both (its fused kernel is its own)."""
+@pytest.mark.parametrize("wb,p,g", [(4, 3221225473, 5), (4, 2013265921, 31), (4, 998244353, 3), (4, 3329, 3), (8, GOLD, 7),
+                                     (8, 0x3FFFFFEE00000001, 3)])
+def test_wide_variant_of_single_pass_sizes(eng, oracle, wb, p, g):
+    """N = 2^10 .. 2^12, both word widths: alternative 0 runs the unit on 512 threads x 8 words (variant 1) below a batch
+    threshold, alternative 1 the default radix-16 kernel from it on.  Both pinned and through the batch rule: forward, both layouts
+    (the AIE_BLOCK16 legs keep the default kernel), inverse (8-byte: N^-1 folded into stage 0 of the wide kernel too), unscaled
+    inverse, in place, ragged batches, every 4-byte modulus class, Goldilocks and the general 64-bit modulus; the negacyclic
+    product under both (its fused kernel is its own)."""
     from ntt_aie_amd import _lib
 
     L = _lib.lib()
-    dt = np.uint32
+    dt = np.uint32 if wb == 4 else np.uint64
     for logn in (10, 11, 12):
         n = 1 << logn
-        T = oracle.make_roots(n, p, g, 4)
-        pl = eng.NTTPlan(logn, p, 4, 0)
+        T = oracle.make_roots(n, p, g, wb)
+        pl = eng.NTTPlan(logn, p, wb, 0)
         pl.set_twiddles(T)
         alts = pl.alternatives
         assert [a[0] for a in alts] == [[logn], [logn]] and alts[0][1] == 0 and alts[1][1] >= 256
@@ -338,7 +340,7 @@ def test_wide_variant_of_4byte_single_pass_sizes(eng, oracle, p, g):
             assert np.array_equal(eng.to_host(pl.inverse(f)), a), batch
     if (p - 1) % (1 << 13) == 0:  # a negacyclic table exists: the product under both alternatives
         logn, n = 12, 4096
-        pl = eng.NTTPlan(logn, p, 4, 0)
+        pl = eng.NTTPlan(logn, p, wb, 0)
         T2 = pl.make_table(2, g)
         pl.set_twiddles(T2)
         a, b = _rand(5, n, p, dt, 1), _rand(5, n, p, dt, 2)
@@ -348,3 +350,33 @@ def test_wide_variant_of_4byte_single_pass_sizes(eng, oracle, p, g):
             pl.set_policy(k)
             c = pl.polymul_negacyclic(eng.to_device(a, "cuda:0"), eng.to_device(b, "cuda:0"))
             assert np.array_equal(eng.to_host(c), want), k
+
+
+def test_multi_device_plan_scatter_transform_gather(eng, oracle):
+    """ntt_aie_amd.multi.MultiDevicePlan: one process, one plan clone + one stream per device, contiguous rows per device
+    (three clones on device 0 here).  Scatter a ragged [37][N] job, transform every shard, gather: the oracle's words; the
+    inverse gives the input back; empty shards (more devices than rows) are no-ops."""
+    from ntt_aie_amd import MultiDevicePlan
+
+    p, logn = GOLD, 13
+    n = 1 << logn
+    md = MultiDevicePlan(logn, p, 8, devices=[0, 0, 0])
+    with pytest.raises(RuntimeError):
+        md.forward([])
+    T = md.make_table(0, 7)
+    md.set_twiddles(T)
+    assert md.rows(37) == [(0, 13), (13, 25), (25, 37)] and len(md.plans) == 3 and len({id(s) for s in md.streams}) == 3
+    a = _rand(37, n, p, np.uint64, 5)
+    shards = md.scatter(a)
+    assert [s.shape[0] for s in shards] == [13, 12, 12]
+    f = md.forward(shards)
+    assert np.array_equal(md.gather(f), oracle.ntt(a, T, p, nthreads=8))
+    assert np.array_equal(md.gather(md.inverse(f)), a)
+    blk = md.forward(shards, layout=eng.LAYOUT_AIE_BLOCK16)
+    assert np.array_equal(md.gather(blk), oracle.block16(oracle.ntt(a, T, p, nthreads=8)))
+    two = md.scatter(a[:2])  # rows (0,1), (1,2), (2,2): the last device holds nothing
+    assert [s.shape[0] for s in two] == [1, 1, 0]
+    assert np.array_equal(md.gather(md.forward(two)), oracle.ntt(a[:2], T, p))
+    md.generate_twiddles(0, 7)  # re-made on the first device and cloned again
+    assert np.array_equal(md.gather(md.forward(shards)), oracle.ntt(a, T, p, nthreads=8))
+    md.close()
