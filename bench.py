@@ -625,6 +625,7 @@ def run_single_process(args):
         with torch.cuda.device(d):
             xs.append(synth_batch(torch, batch, n, torch.device("cuda", d), first_row=i * batch))  # shard i = rows [i*batch, (i+1)*batch) of the job
             ys.append(torch.empty_like(xs[-1]))
+            torch.cuda.synchronize(d)  # the generator ran on the device's default stream; the transforms run on the shard's own stream
 
     def step():
         for pl, x, y, st in zip(plans, xs, ys, streams):

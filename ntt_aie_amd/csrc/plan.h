@@ -90,7 +90,7 @@ inline std::vector<PassDesc> plan_passes(int n, int word_bytes = 8) {
         // re-swept on the final kernels of round 2 (tools/split_sweep.py over every split, then same-process confirmation of the
         // candidates: profiles/r02_split_sweep_final.txt): 8-byte 2^15 = 7 + 8 (-1.5 .. -2.2 % against 8 + 7); 4-byte 2^15 = 9 + 6
         // (-0.6 % for a 32-bit prime, -4.7 % for a lazy one), 2^16 = 10 + 6 (+1.5 % / -7.2 %), 2^19 = 11 + 8 (-4.3 % / -1.3 .. -2.3 %)
-        static const int first_w8[8] = {7, 8, 7, 8, 9, 10, 11, 12};  // (9,7) wins N = 2^16 at batch 8192 but loses at 4096
+        static const int first_w8[8] = {7, 8, 7, 8, 9, 10, 11, 12};  // N = 2^16 per 4 GiB (batch 8192): 8 + 8 3.311 ms, 9 + 7 3.339, 10 + 6 3.492 (r02_split_sweep_final.txt)
         static const int first_w4[8] = {8, 8, 9, 10, 10, 10, 11, 12};
         const int first = (word_bytes == 8 ? first_w8 : first_w4)[n - MAX_CONTIG_LOG_M - 1];
         v.push_back({true, 0, first});
