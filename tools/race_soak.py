@@ -16,7 +16,11 @@ shapes = [(4, 3221225473, 5, 12, 4099), (4, 998244353, 3, 13, 2053), (4, 3221225
           # round 3: the 13-stage alternative of 8-byte N = 2^13 and the 14-stage one of lazy 4-byte N = 2^14 (batches above their thresholds),
           # the 9-stage column pass (N = 2^22, three fields), the general 64-bit modulus (generated streams, folded scaling)
           (8, B.GOLD, 7, 13, 1031), (4, 998244353, 3, 14, 1031), (8, B.GOLD, 7, 22, 5), (4, 998244353, 3, 22, 9), (4, 3221225473, 5, 22, 2),
-          (8, 0x3FFFFFEE00000001, 3, 16, 517), (8, 0xFFFFFFFC00000001, 10, 12, 2053), (8, 0x3FFFFFEE00000001, 3, 21, 5)]
+          (8, 0x3FFFFFEE00000001, 3, 16, 517), (8, 0xFFFFFFFC00000001, 10, 12, 2053), (8, 0x3FFFFFEE00000001, 3, 21, 5),
+          # round 4: the 512-thread x 8-word variant of the single-pass sizes (batches below its threshold: four exchanges, the last
+          # one across waves at 2^12), every 4-byte modulus class, Goldilocks (LDS-DMA forward as the only pass) and the general modulus
+          (4, 3221225473, 5, 12, 1031), (4, 2013265921, 31, 11, 517), (4, 998244353, 3, 12, 257), (4, 3221225473, 5, 10, 2047),
+          (8, B.GOLD, 7, 12, 1031), (8, B.GOLD, 7, 10, 2047), (8, 0x3FFFFFEE00000001, 3, 12, 517)]
 bad = 0
 for wb, p, g, logn, batch in shapes:
     n = 1 << logn
