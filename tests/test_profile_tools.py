@@ -231,3 +231,16 @@ def test_config_summary_per_operation(tmp_path):
     s2 = CS.summarize_sq("cfg2", 1, str(ps), src_hash="abc")
     (e,) = s2["kernels"].values()
     assert e["launches"] == 1 and e["valu_instr_per_butterfly"] == pytest.approx(12.0) and e["held_clock_GHz"] == pytest.approx(30000.0 / 14000)
+
+
+def test_design_md_tables_are_what_the_profiles_say():
+    """DESIGN.md section 4's two tables live between <!-- generated:... --> markers and are written by tools/design_table.py
+    from profiles/<round>_*: regenerating them from the committed profile set must reproduce the committed text exactly
+    (the document cannot drift from the files it cites)."""
+    import importlib
+
+    dt = importlib.import_module("design_table")
+    s = open(os.path.join(ROOT, "DESIGN.md")).read()
+    spread = s.split("ms per step** (", 1)[1].split(") |", 1)[0]
+    again = dt.replace(dt.replace(s, "headline", dt.headline(spread)), "configs", dt.configs())
+    assert again == s
