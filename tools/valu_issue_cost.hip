@@ -1,5 +1,5 @@
 // valu_issue_cost.hip -- issue cost, in SHADER CYCLES per wave-instruction per SIMD, of every VALU form the Goldilocks
-// butterfly streams (csrc/gl_asm.h) are made of, and of the streams themselves, at 1 / 2 / 4 / 8 waves per SIMD.
+// butterfly streams (csrc/gl_asm.h) are made of (1 .. 8 waves per SIMD), and of the streams themselves (1 .. 4: they pin v104+).
 //
 // Why: bench.py's VALU roofline priced every VALU instruction at 4 cycles.  The forms differ:
 // gfx950's vector ALU retires plain 32-bit ops of a wave64 in 2 cycles once two waves share the SIMD, VOP3 carry forms in 4,
@@ -241,7 +241,7 @@ int main() {
     for (int f = 0; f < nforms; f++) {
         printf("  \"%s\": {\"class\": \"%s\", \"cycles\": {", forms[f].name, forms[f].klass);
         std::string ns = "", ghz = "";
-        for (int w = 1, first = 1; w <= 8; w *= 2, first = 0) {
+        for (int w = 1, first = 1; w <= 8; w += 1, first = 0) {
             Result r = run(forms[f].k, w, forms[f].instr_per_iter * ITERS, d_out, d_st, h_st);
             printf("%s\"%d\": %.3f", first ? "" : ", ", w, r.cycles_per_instr);
             char buf[64];
@@ -270,7 +270,7 @@ int main() {
     for (int f = 0; f < nstreams; f++) {
         printf("  \"%s\": {\"valu_per_butterfly\": %.0f, \"cycles_per_butterfly\": {", streams[f].name, streams[f].valu_per_butterfly);
         std::string ghz = "";
-        for (int w = 1, first = 1; w <= 4; w *= 2, first = 0) {  // 128 VGPRs: at most 4 waves per SIMD, like the kernels (3.7 measured)
+        for (int w = 1, first = 1; w <= 4; w += 1, first = 0) {  // 128 VGPRs: at most 4 waves per SIMD, like the kernels (3.7 measured)
             Result r = run(streams[f].k, w, 12.0 * ITERS, d_out, d_st, h_st);
             printf("%s\"%d\": %.2f", first ? "" : ", ", w, r.cycles_per_instr);
             char buf[64];
