@@ -454,17 +454,47 @@ NTT_HD void phase_begin_iter(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     c.active = Cfg::LOG_U == 0 ? true : poly < a.batch;
 }
 
-// element number as seen by the transform-domain layout: in the pass that holds the
-// top stage the 4-bit window of the outermost round IS the 16-block index of
-// src/test.cpp:69-71, so the block permutation is a compile-time renumbering.
+// Word offset of element e of a thread's direct load / store in round r (window win(r), pass offset s0), as seen by the
+// transform-domain layout.  Natural order: e << (win + s0).  AIE_BLOCK16 (src/test.cpp:69-71), in the pass that holds the top stage:
+//   radix-16 rounds: the 4-bit window of the outermost round IS the 16-block index, so the block permutation is a compile-time
+//     renumbering of e;
+//   radix-8 rounds (the 512-thread variant of the single-pass sizes): the window holds the block index's top three bits
+//     (e2 e1 e0) and the thread holds the fourth (t = the top bit of its mid part).  ans_order swaps the bits inside each 2-bit
+//     half, (e2 e1 e0 t) -> (e1 e2 t e0): e1 e2 move inside the window, e0 drops to the bit below it, and t rises from that bit
+//     into the window's lowest place -- a per-element constant plus a per-thread shift of ONE address bit (lane_eff below).
+// which radix-8 kernels can hold the top stage at all: the 512-thread ones of 10..12 stages (the only pass of the single-pass sizes;
+// as the first pass of a two-pass plan the run-time test below is false).  The 256-thread ones (7..9 stages: the headline's first
+// pass) never do, and carry no trace of the layout.
 template <class Cfg>
-NTT_HD uint32_t elem_eff(const PassArgs<Cfg> &a, int e, bool want) {
+constexpr bool radix8_layout() {
+    return Cfg::LOG_E == 3 && Cfg::LOG_NT == 9 && Cfg::LOG_M >= 10 && Cfg::CONTIG;
+}
+template <class Cfg>
+NTT_HD bool layout_here(const PassArgs<Cfg> &a, bool want) {
+    return want && a.layout == LAYOUT_AIE_BLOCK16 && (a.s0 + Cfg::LOG_M == a.n);
+}
+template <class Cfg>
+NTT_HD uint32_t elem_off(const PassArgs<Cfg> &a, int e, bool want, int r) {
+    const int sh = Cfg::win(r) + a.s0;
     if constexpr (Cfg::LOG_E == 4) {
-        const bool perm = want && a.layout == LAYOUT_AIE_BLOCK16 && (a.s0 + Cfg::LOG_M == a.n);
-        return perm ? aie_block16((uint32_t) e) : (uint32_t) e;
+        return (layout_here<Cfg>(a, want) ? aie_block16((uint32_t) e) : (uint32_t) e) << sh;
+    } else if constexpr (radix8_layout<Cfg>()) {
+        if (layout_here<Cfg>(a, want)) {
+            const uint32_t e2 = ((uint32_t) e >> 2) & 1u, e1 = ((uint32_t) e >> 1) & 1u, e0 = (uint32_t) e & 1u;
+            return (((e1 << 2) | (e2 << 1)) << sh) | (e0 << (sh - 1));
+        }
+        return (uint32_t) e << sh;
     } else {
-        return (uint32_t) e;
+        return (uint32_t) e << sh;
     }
+}
+// the lane's own word offset under the layout: radix-8 rounds move the thread's block bit t from address bit (sh - 1) to bit sh
+template <class Cfg>
+NTT_HD uint32_t lane_eff(const PassArgs<Cfg> &a, uint32_t lane_word, bool want, int r) {
+    if constexpr (radix8_layout<Cfg>()) {
+        if (layout_here<Cfg>(a, want)) return lane_word + (lane_word & (1u << (Cfg::win(r) + a.s0 - 1)));
+    }
+    return lane_word;
 }
 
 // Cache policy of the streamed coefficient traffic (aux bits of the buffer instructions: 2 = nt).
@@ -516,27 +546,28 @@ NTT_HD void phase_load_direct_to(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it, ty
 #if defined(__HIP_DEVICE_COMPILE__)
     // element offsets stay below 2^32 bytes: (E-1) << (n - LOG_E) words at most
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) ubase, 0, -1, 0x00020000);
-    const uint32_t voff = c.lane_ld * (uint32_t) sizeof(W);
+    const uint32_t voff = lane_eff<Cfg>(a, c.lane_ld, Cfg::INV, r) * (uint32_t) sizeof(W);
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
-        const uint32_t so = (elem_eff<Cfg>(a, e, Cfg::INV) << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W);
+        const uint32_t so = elem_off<Cfg>(a, e, Cfg::INV, r) * (uint32_t) sizeof(W);
         dstx[e] = (W) 0;
         if (active) dstx[e] = buf_load<W>(rs, voff, so);
     }
     if (Cfg::CONTIG && !Cfg::INV && a.in2 != nullptr) {
         const __amdgpu_buffer_rsrc_t rs2 =
             __builtin_amdgcn_make_buffer_rsrc((void *) (a.in2 + uniform_word<Cfg>(c, a, it)), 0, -1, 0x00020000);
+        const uint32_t voff2 = c.lane_ld * (uint32_t) sizeof(W);  // (forward pass: its input is in natural order whatever the layout)
 #pragma unroll
         for (int e = 0; e < Cfg::E; ++e) {
             const uint32_t so = ((uint32_t) e << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W);
-            if (active) dstx[e] = a.field.mul(a.field.mul(dstx[e], buf_load<W>(rs2, voff, so)), a.pw_scale);
+            if (active) dstx[e] = a.field.mul(a.field.mul(dstx[e], buf_load<W>(rs2, voff2, so)), a.pw_scale);
         }
     }
 #else
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
-        const size_t eo = (size_t) elem_eff<Cfg>(a, e, Cfg::INV) << (Cfg::win(r) + a.s0);
-        dstx[e] = active ? (ubase + eo)[c.lane_ld] : (W) 0;
+        const size_t eo = (size_t) elem_off<Cfg>(a, e, Cfg::INV, r);
+        dstx[e] = active ? (ubase + eo)[lane_eff<Cfg>(a, c.lane_ld, Cfg::INV, r)] : (W) 0;
         if (Cfg::CONTIG && !Cfg::INV && a.in2 != nullptr && active)
             dstx[e] = a.field.mul(a.field.mul(dstx[e], (a.in2 + uniform_word<Cfg>(c, a, it) + eo)[c.lane_ld]), a.pw_scale);
     }
@@ -557,7 +588,7 @@ NTT_HD void phase_store_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     if (a.dbg & 2) return;
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t voff = c.lane_st * (uint32_t) sizeof(W);
+    const uint32_t voff = lane_eff<Cfg>(a, c.lane_st, !Cfg::INV, r) * (uint32_t) sizeof(W);
     if constexpr (Cfg::DMA) {
         // The LDS-DMA wait of the next iteration counts on EXACTLY E store instructions being
         // younger than the prefetch (phase_dma_wait): issue them by hand so that no compiler
@@ -573,7 +604,7 @@ NTT_HD void phase_store_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
         asm volatile("s_nop 4" ::: "memory");  // v_readfirstlane -> VMEM descriptor read
 #pragma unroll
         for (int e = 0; e < Cfg::E; ++e) {
-            const uint32_t so = __builtin_amdgcn_readfirstlane((elem_eff<Cfg>(a, e, !Cfg::INV) << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W));
+            const uint32_t so = __builtin_amdgcn_readfirstlane(elem_off<Cfg>(a, e, !Cfg::INV, r) * (uint32_t) sizeof(W));
             asm volatile("buffer_store_dwordx2 %0, %1, %2, %3 offen nt" ::"v"(c.x[e]), "v"(voff), "s"(srd), "s"(so) : "memory");
         }
         return;
@@ -581,14 +612,14 @@ NTT_HD void phase_store_direct(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *) ubase, 0, -1, 0x00020000);
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
-        const uint32_t so = (elem_eff<Cfg>(a, e, !Cfg::INV) << (Cfg::win(r) + a.s0)) * (uint32_t) sizeof(W);
+        const uint32_t so = elem_off<Cfg>(a, e, !Cfg::INV, r) * (uint32_t) sizeof(W);
         buf_store<W>(c.x[e], rs, voff, so);
     }
 #else
 #pragma unroll
     for (int e = 0; e < Cfg::E; ++e) {
-        const size_t eo = (size_t) elem_eff<Cfg>(a, e, !Cfg::INV) << (Cfg::win(r) + a.s0);
-        (ubase + eo)[c.lane_st] = c.x[e];
+        const size_t eo = (size_t) elem_off<Cfg>(a, e, !Cfg::INV, r);
+        (ubase + eo)[lane_eff<Cfg>(a, c.lane_st, !Cfg::INV, r)] = c.x[e];
     }
 #endif
 }
@@ -779,7 +810,8 @@ NTT_HD void phase_dma_wait() {
 #endif
 }
 
-// does this pass see the transform-domain layout AIE_BLOCK16 (elem_eff): the pass that holds the top stage, radix-16 rounds
+// does a LINEARLY STAGED tile of this pass see the transform-domain layout AIE_BLOCK16: the pass that holds the top stage, radix-16 rounds
+// (the radix-8 kernels load / store the layout directly: elem_off / lane_eff)
 template <class Cfg>
 NTT_HD bool block16_here(const PassArgs<Cfg> &a) {
     return Cfg::LOG_E == 4 && a.layout == LAYOUT_AIE_BLOCK16 && (a.s0 + Cfg::LOG_M == a.n);

@@ -299,7 +299,7 @@ int dispatch(bool contig, int log_m, const Erased &e) {
             else return -1;
         }
         // pass_kernel.inc: the wide radix-8 variant of the single-pass sizes 2^10 .. 2^12 (same conditions as there)
-        if (e.variant == 1 && e.in2 == nullptr && !(e.layout == LAYOUT_AIE_BLOCK16 && e.s0 + log_m == e.n)) {
+        if (e.variant == 1 && e.in2 == nullptr) {
             if (log_m == 10) return run_cfg<PassCfg<F, 10, 0, true, INV, 0xF, 3, 9>>(e);
             if (log_m == 11) return run_cfg<PassCfg<F, 11, 0, true, INV, 0xF, 3, 9>>(e);
             if (log_m == 12) return run_cfg<PassCfg<F, 12, 0, true, INV, 0xF, 3, 9>>(e);

@@ -313,7 +313,7 @@ def test_wide_radix8_variant_of_the_single_pass_sizes(oracle, wb, p, g):
     """PassDesc::variant 1 (round 4): a single-pass unit of 2^10 .. 2^12 words on 512 threads x 8 words -- radix-8 rounds of
     3 + 3 + 3 + (1..3) stages (8-byte forward: the LDS-DMA kernel, here as the LAST pass of a plan) -- instead of 256 x 16.
     Every 4-byte modulus class (32-bit, 31-bit, lazy), Goldilocks and the general 64-bit modulus, both directions (the scaled
-    inverse folds N^-1 into stage 0 for 8-byte words), both layouts (AIE_BLOCK16 keeps the default kernel), ragged batch and in
+    inverse folds N^-1 into stage 0 for 8-byte words), both layouts (the block permutation of a radix-8 round: pass.h elem_off / lane_eff), ragged batch and in
     place, under the LDS hazard tracker; 4-byte: as the first pass of a two-pass plan as well."""
     wide = 1 << 60
     for logn in (10, 11, 12):

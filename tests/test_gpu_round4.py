@@ -311,7 +311,7 @@ def _check_all_legs(eng, oracle, pl, T, p, dt, batches, seed):
 def test_wide_variant_of_single_pass_sizes(eng, oracle, wb, p, g):
     """N = 2^10 .. 2^12, both word widths: alternative 0 runs the unit on 512 threads x 8 words (variant 1) below a batch
     threshold, alternative 1 the default radix-16 kernel from it on.  Both pinned and through the batch rule: forward, both layouts
-    (the AIE_BLOCK16 legs keep the default kernel), inverse (8-byte: N^-1 folded into stage 0 of the wide kernel too), unscaled
+    (AIE_BLOCK16 straight from the radix-8 kernel: one address bit moves between the register index and the thread), inverse (8-byte: N^-1 folded into stage 0 of the wide kernel too), unscaled
     inverse, in place, ragged batches, every 4-byte modulus class, Goldilocks and the general 64-bit modulus; the negacyclic
     product under both (its fused kernel is its own)."""
     from ntt_aie_amd import _lib
