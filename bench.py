@@ -408,13 +408,21 @@ def self_launch(args, argv):
                              "(NTT_BENCH_ONE_DEVICE=1 NTT_BENCH_BACKEND=gloo rehearses the launch path on one device)\n"
                              % (args.gpus, have))
             return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    proc = None
+    for _ in range(4):
+        # a free port is probed, released and handed to the launcher: another process can take it in between (EADDRINUSE) --
+        # then, and only then, the launch is repeated on a new port
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        collided = proc.returncode != 0 and ("EADDRINUSE" in proc.stderr or "address already in use" in proc.stderr.lower())
+        if not collided:
+            break
+    sys.stderr.write(proc.stderr)
     sys.stdout.write(proc.stdout)
     sys.stdout.flush()
     return proc.returncode

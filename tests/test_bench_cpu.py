@@ -2,14 +2,12 @@
 coefficient-sum invariant's arithmetic, the weighted VALU issue model on a synthetic mix, and the tools that feed it."""
 import json
 import os
-import socket
 import sys
 
 import numpy as np
 import pytest
-import torch.multiprocessing as mp
 
-from conftest import ROOT
+from conftest import ROOT, spawn_world
 
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
@@ -32,21 +30,17 @@ def test_rowsum_mod_p_is_exact_and_is_the_networks_output_zero(oracle):
     assert [int(v) for v in out[:, 0]] == want
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def _reduce_worker(rank, world, port, bad_rank, q):
+def _reduce_worker(rank, world, port, q, bad_rank):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
     import torch.distributed as dist
 
     import bench
+    from conftest import init_gloo_or_report
 
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if not init_gloo_or_report(rank, world, port, q):
+        return
     ok = rank != bad_rank
     ident = {"rank": rank, "local_device": rank, "pci_bus_id": "0000:%02x:00.0" % (5 + rank), "ms_per_step": 1.5 + rank,
              "round_trip_identical": ok, "coefficient_sum_invariant": True}
@@ -61,16 +55,7 @@ def test_one_bad_rank_turns_the_line_red(bad_rank):
     """world-2 gloo: every rank contributes (round trip ok, coefficient sum ok) + its identity; all_reduce(MIN) + all_gather.
     With every rank good: all_ranks_verified, exit code 0.  With ONE bad rank -- whichever -- every rank learns it, rank 0's
     line says false and every process exits 1."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_reduce_worker, args=(r, 2, port, bad_rank, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted((q.get(timeout=180) for _ in procs), key=lambda r: r[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = spawn_world(_reduce_worker, 2, extra_args=(bad_rank,))
     for rank, code, f in res:
         assert f["world_size_seen"] == 2 and [r["rank"] for r in f["ranks"]] == [0, 1]  # gathered in rank order
         assert f["distinct_devices"] == 2 and [r["ms_per_step"] for r in f["ranks"]] == [1.5, 2.5]

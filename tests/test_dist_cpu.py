@@ -1,32 +1,23 @@
 """world_size-2 rehearsal of the multi-GPU path on CPU (gloo): batch sharding and
 the one collective of the design, the twiddle-table broadcast."""
 import os
-import socket
 import sys
 
 import numpy as np
-import torch.multiprocessing as mp
 
-from conftest import ROOT
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+from conftest import ROOT, spawn_world
 
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
 
+    from conftest import init_gloo_or_report
     from ntt_aie_amd import dist as nd
 
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if not init_gloo_or_report(rank, world, port, q):
+        return
     n = 1 << 10
     table = (np.arange(n, dtype=np.uint64) * 0x9E3779B97F4A7C15 + 12345) if rank == 0 else None
     got = nd.broadcast_table(table, n, 8, src=0)
@@ -50,16 +41,7 @@ def test_shard_rows_partition():
 
 
 def test_gloo_world2_broadcast_and_shards():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=180) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = spawn_world(_worker, 2)
     n = 1 << 10
     want = int((np.arange(n, dtype=np.uint64) * 0x9E3779B97F4A7C15 + 12345).sum(dtype=np.uint64))
     want32 = int((np.arange(n, dtype=np.uint32) * 2654435761 + 7).sum(dtype=np.uint64))

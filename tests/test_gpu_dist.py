@@ -11,7 +11,7 @@ import sys
 
 import pytest
 
-from conftest import ROOT
+from conftest import ROOT, run_with_fresh_port
 
 pytestmark = pytest.mark.gpu
 
@@ -29,9 +29,9 @@ def _env(port: int) -> dict:
 
 def test_bench_force_dist_nccl_world1():
     """bench.py with --force-dist: the nccl branch of bench.py and of dist.broadcast_table run end to end."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2",
-                          "--warmup", "1", "--batch", "64", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=900, env=_env(_free_port()))
+    out = run_with_fresh_port(lambda port: subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--batch", "64",
+         "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=_env(port)))
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["steps"] == 2
@@ -66,5 +66,6 @@ def test_broadcast_table_under_nccl_group(tmp_path):
         "assert np.array_equal(to_host(eng.inverse_local(f)), a)\n"
         "dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()\n"
         "print('NCCL_BCAST_OK')\n" % (ROOT, ROOT))
-    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=_env(_free_port()))
+    out = run_with_fresh_port(lambda port: subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900,
+                                                          env=_env(port)))
     assert out.returncode == 0 and "NCCL_BCAST_OK" in out.stdout, (out.stdout + out.stderr)[-3000:]

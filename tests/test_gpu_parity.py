@@ -415,20 +415,16 @@ def test_bench_two_ranks_rehearsal():
     table broadcast from rank 0, per-rank shards, barrier + max-over-ranks timing, the one JSON line
     of rank 0 with the whole-job aggregate -- is the code the 8-GPU run executes."""
     import json
-    import socket
     import subprocess
     import sys
 
-    from conftest import ROOT
+    from conftest import ROOT, run_with_fresh_port
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, NTT_BENCH_ONE_DEVICE="1", NTT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256"],
-                         capture_output=True, text=True, timeout=900, env=env)
+    out = run_with_fresh_port(lambda port: subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256"],
+        capture_output=True, text=True, timeout=900, env=env))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # rank 0 only
