@@ -36,12 +36,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GOLDILOCKS = 0xFFFFFFFF00000001
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s achievable by a float4 copy
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from hw import HBM_PEAK_GBS, PEAK_CLOCK_GHZ, SIMDS, VALU_PEAK_CYCLES_PER_WAVE_INSTR  # noqa: E402  (tools/hw.py: the one place the peaks live)
+
 SEED = 0x9E3779B97F4A7C15  # a[b][i] = splitmix64(SEED + b*N + i) mod p
-PROFILE_ROUND = "r04"
-SIMDS = 1024            # 256 CUs x 4 SIMDs
-PEAK_CLOCK_GHZ = 2.4    # MI355X_MICROARCH.md: peak engine clock
-VALU_CYCLES_PER_WAVE_INSTR = 4  # one wave64 instruction on a 16-lane SIMD (assumed for EVERY VALU form: see roofline.valu.what)
+PROFILE_ROUND = "r04"  # the collection DESIGN.md section 4 is generated from (tools/design_table.py); counters are quoted from the newest matching round (tagged_profile)
 
 
 def _s64(v: int) -> int:
@@ -90,14 +89,15 @@ def host_cores():
     return aff, quota
 
 
-def cpu_baseline(logn, p, table, rows_fn, cpu_seconds=20.0, threads=None):
+def cpu_baseline(logn, p, table, rows_fn, batch, cpu_seconds=20.0, threads=None):
     """Oracle (port of the reference CPU verification path, src/test.cpp:34-60: three `%` per butterfly) on the host cores,
     bounded sample: one thread (the reference is single-threaded) and ALL the cores this process may run on,
     one polynomial per task; the count is stated next to the figure.
 
-    The sample is the GPU's own input (the reference runs its CPU path on the same a[i] it handed the device,
-    src/test.cpp:203-207): `rows_fn(k)` returns rows [0, k) of the job's synthetic batch as a host uint64 array -- the first
-    rows of the resident device buffer copied back, continued by the same generator when the sample is longer than the batch."""
+    The sample is the GPU's own input and nothing else (the reference runs its CPU path on exactly the a[i] it handed the
+    device, src/test.cpp:203-207): `rows_fn(k)` returns rows [0, k) of the resident device buffer copied back, k <= batch.  The
+    sample is sized for about `cpu_seconds` of CPU work and CAPPED at the batch: a host fast enough to want more rows simply
+    finishes sooner (`rows_beyond_gpu_batch` is 0 by construction and says so in the line)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
 
@@ -107,13 +107,15 @@ def cpu_baseline(logn, p, table, rows_fn, cpu_seconds=20.0, threads=None):
     # shows all 256 host threads but the container is throttled to 16 cores: 256 OpenMP threads then run slower than 16)
     avail = aff if not quota else max(1, min(aff, int(quota + 0.999)))
     cores = int(threads) if threads else avail
-    probe = rows_fn(2)
+    probe = rows_fn(min(2, batch))
     t0 = time.perf_counter()
     O.ntt(probe, table, p, nthreads=1)
-    t1 = (time.perf_counter() - t0) / 2
+    t1 = (time.perf_counter() - t0) / len(probe)
     rate_1 = 1.0 / t1
-    # bounded sample: about `cpu_seconds` of CPU work in total, spread over the host threads (at least 4 polynomials per thread)
-    sample = int(max(cores * 4, min(16384, cpu_seconds / t1)))
+    # bounded sample: about `cpu_seconds` of CPU work in total, spread over the host threads (at least 4 polynomials per thread
+    # when the batch has them), never more rows than the GPU transformed
+    want = int(max(cores * 4, min(16384, cpu_seconds / t1)))
+    sample = max(1, min(want, batch))
     a = rows_fn(sample)
     t0 = time.perf_counter()
     O.ntt(a, table, p, nthreads=cores)
@@ -121,11 +123,12 @@ def cpu_baseline(logn, p, table, rows_fn, cpu_seconds=20.0, threads=None):
     rate_n = sample / tn
     best, used = (rate_n, cores) if rate_n >= rate_1 else (rate_1, 1)
     return {"value": best, "unit": "NTT/s", "cores": used, "kind": "port",
-            "sample": "rows 0..%d of the GPU's own input batch (same seed, same generator, same table), N=2^%d, on %d threads "
+            "sample": "rows 0..%d of the GPU's own resident input batch (copied back from the device), N=2^%d, on %d threads "
                       "(%.2f s) -- every core available to this process: affinity mask %d%s; 1-thread rate %.1f NTT/s"
                       % (sample - 1, logn, cores, tn, aff,
                          (", cgroup CPU quota %.1f cores" % quota) if quota else ", no cgroup quota", rate_1),
-            "sample_rows": sample, "sample_is_gpu_input": True,
+            "sample_rows": sample, "sample_is_gpu_input": True, "rows_beyond_gpu_batch": 0,
+            "sample_rows_wanted_for_%ds" % int(cpu_seconds): want, "sample_capped_at_batch": bool(want > batch),
             "host_affinity_cores": aff, "host_cgroup_quota_cores": quota, "host_available_cores": avail, "threads_all_cores_leg": cores,
             "value_all_cores": rate_n, "value_1thread": rate_1, "butterflies_per_s": best * (n // 2) * logn}
 
@@ -194,15 +197,26 @@ def valu_floor(torch, logn, p, batch, x, y, stream, reps=5):
 
 
 def tagged_profile(name, src_hash):
-    """profiles/<round>_<name>.json if it was collected on exactly these kernel sources, else (None, reason)."""
-    path = os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_ROUND, name))
-    if not os.path.exists(path):
-        return None, "profiles/%s_%s.json absent" % (PROFILE_ROUND, name)
-    d = json.load(open(path))
-    if d.get("src_hash") != src_hash:
-        return None, "profiles/%s_%s.json was collected on kernel sources %s, this tree is %s: not quoted" % (
-            PROFILE_ROUND, name, d.get("src_hash"), src_hash)
-    return d, "profiles/%s_%s.json (src_hash %s)" % (PROFILE_ROUND, name, src_hash)
+    """The newest profiles/rNN_<name>.json that was collected on exactly these kernel sources, else (None, reason).
+    Rounds are searched newest first (the current collection tag PROFILE_ROUND, then older ones): a round that did not touch
+    the kernels keeps quoting the previous round's counters, a round that did quotes nothing until it has re-collected."""
+    import glob
+    import re
+
+    cands = []
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s.json" % name)):
+        m = re.match(r"r(\d\d)_", os.path.basename(path))
+        if m and os.path.basename(path) == "r%s_%s.json" % (m.group(1), name):
+            cands.append((int(m.group(1)), path))
+    if not cands:
+        return None, "profiles/rNN_%s.json absent" % name
+    seen = []
+    for _, path in sorted(cands, reverse=True):
+        d = json.load(open(path))
+        if d.get("src_hash") == src_hash:
+            return d, "profiles/%s (src_hash %s)" % (os.path.basename(path), src_hash)
+        seen.append("%s: %s" % (os.path.basename(path), d.get("src_hash")))
+    return None, "no profiles/rNN_%s.json was collected on kernel sources %s (%s): not quoted" % (name, src_hash, "; ".join(seen))
 
 
 def forward_counters(summary, passes, field="FieldGL"):
@@ -220,7 +234,8 @@ def forward_counters(summary, passes, field="FieldGL"):
     return out, None
 
 
-def weighted_issue_cycles(stream_mix, instr_per_butterfly, costs, overhead_cycles=4.0, default_cycles=4.0):
+def weighted_issue_cycles(stream_mix, instr_per_butterfly, costs, overhead_cycles=VALU_PEAK_CYCLES_PER_WAVE_INSTR,
+                          default_cycles=VALU_PEAK_CYCLES_PER_WAVE_INSTR):
     """Issue cycles per wave-butterfly of one pass kernel: the butterfly stream's instructions priced by class with MEASURED
     cycles per wave-instruction (profiles/rNN_valu_issue_cost.json), plus the instructions the counter sees beyond the stream
     (SQ_INSTS_VALU per butterfly - stream length: addressing, register moves) at `overhead_cycles` each.
@@ -231,70 +246,107 @@ def weighted_issue_cycles(stream_mix, instr_per_butterfly, costs, overhead_cycle
 
 
 def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, issue_model=None):
-    """The vector-ALU roofline of the forward transform (the unit that binds).
-    peak butterflies/s = SIMDs x clock / (4 cycles x VALU instructions per butterfly) x 64 lanes.
-    issue_model = {"costs": {class: cycles}, "streams": [stream mix per pass], "source": "..."} adds the WEIGHTED figure:
-    every instruction class priced at its measured issue cost instead of a flat 4 cycles."""
+    """The vector-ALU roofline of the forward transform, on the SIMD-32 peak (tools/hw.py; MI355X_MICROARCH.md: a wave64 VALU
+    instruction takes 2 cycles of a SIMD's throughput).
+      peak butterflies/s = SIMDs x clock / (2 cycles x VALU instructions per butterfly) x 64 lanes
+      frac_of_peak_at_held_clock = instructions x 2 cycles x wave-butterflies / (SIMDs x the launch's shader cycles): clock-free
+    issue_model = {"costs": {class: cycles at the kernels' occupancy}, "streams": [stream mix per pass], ...} adds a SECOND figure,
+    named for what it is: `issue_cost_at_kernel_occupancy` -- what the same instructions cost when only ~4 waves share a SIMD
+    (profiles/rNN_valu_issue_cost.json).  That is a property of the kernels' occupancy, not the unit's capacity, and is never
+    called a peak."""
     n = 1 << logn
+    cpi = VALU_PEAK_CYCLES_PER_WAVE_INSTR
     bf = [batch * (n // 2) * stages for _, _, stages in passes]            # butterflies per launch of each pass
     ipb = [e[1]["valu_instr_per_butterfly"] for e in sq_entries]          # SQ_INSTS_VALU / wave-butterflies, forward kernels
     mean_ipb = sum(i * b for i, b in zip(ipb, bf)) / sum(bf)
     held = [e[1].get("held_clock_GHz") for e in sq_entries]
     cyc = [e[1].get("kernel_cycles") for e in sq_entries]
+    waves = [e[1].get("mean_waves_per_simd") for e in sq_entries]
+    stall = [e[1].get("wave_issue_stall_frac") for e in sq_entries]
     achieved = sum(bf) / (sum(per_pass_ms) * 1e-3)
 
     def peak(f_ghz, instr):
-        return SIMDS * f_ghz * 1e9 / (VALU_CYCLES_PER_WAVE_INSTR * instr) * 64
+        return SIMDS * f_ghz * 1e9 / (cpi * instr) * 64
 
     out = {
         "instr_per_butterfly": ipb, "instr_per_butterfly_mean": mean_ipb,
+        "peak_cycles_per_wave_instr": cpi,
         "peak_butterflies_per_s": peak(PEAK_CLOCK_GHZ, mean_ipb), "peak_clock_GHz": PEAK_CLOCK_GHZ,
         "achieved_butterflies_per_s": achieved,
-        "frac_at_2.4GHz": achieved / peak(PEAK_CLOCK_GHZ, mean_ipb),
-        "frac_at_2.4GHz_per_pass": [b / (t * 1e-3) / peak(PEAK_CLOCK_GHZ, i) for b, t, i in zip(bf, per_pass_ms, ipb)],
+        "frac_of_peak_at_2.4GHz": achieved / peak(PEAK_CLOCK_GHZ, mean_ipb),
+        "frac_of_peak_at_2.4GHz_per_pass": [b / (t * 1e-3) / peak(PEAK_CLOCK_GHZ, i) for b, t, i in zip(bf, per_pass_ms, ipb)],
         "kernels": [e[0] for e in sq_entries],
+        "mean_waves_per_simd": waves, "wave_issue_stall_frac": stall,
         "what": "instr_per_butterfly = SQ_INSTS_VALU of the FORWARD pass kernels / (butterflies / 64); peak = %d SIMDs x f / "
-                "(%d cycles x instr) x 64 lanes, every VALU form priced at %d cycles; frac_at_2.4GHz uses THIS run's pass durations; "
-                "frac_at_held_clock is clock-free: instr x 4 cycles x wave-butterflies / (SIMDs x GRBM_GUI_ACTIVE/8) of the "
-                "counter run, with held_clock_GHz = GRBM_GUI_ACTIVE / 8 / duration of the same profiled launches; "
-                "frac_at_held_clock_weighted replaces the flat 4 cycles by the measured issue cost of each instruction class "
-                "(tools/valu_issue_cost.hip: plain ops retire in ~2 cycles, VOP3 carry forms in ~4, v_mad_u64_u32 in more)"
-                % (SIMDS, VALU_CYCLES_PER_WAVE_INSTR, VALU_CYCLES_PER_WAVE_INSTR),
+                "(%g cycles x instr) x 64 lanes: a wave64 instruction takes %g cycles on a SIMD-32 (MI355X_MICROARCH.md; the probe "
+                "tools/valu_issue_cost measures 1.9-2.0 for the streams' VOP3 forms at 8 waves per SIMD); frac_of_peak_at_2.4GHz uses THIS "
+                "run's pass durations; frac_of_peak_at_held_clock is clock-free: instr x %g cycles x wave-butterflies / (SIMDs x "
+                "GRBM_GUI_ACTIVE/8) of the counter run, held_clock_GHz = GRBM_GUI_ACTIVE / 8 / duration of the same profiled launches; "
+                "issue_cost_at_kernel_occupancy prices the same instructions with the cycles they cost when only as many waves share a "
+                "SIMD as these kernels run (a property of the occupancy, not a peak)" % (SIMDS, cpi, cpi, cpi),
     }
     if all(h for h in held) and all(c for c in cyc):
         out["held_clock_GHz"] = held
-        out["frac_at_held_clock_per_pass"] = [e[1]["valu_instr_x4cyc_over_kernel_cycles"] for e in sq_entries]
+        per_pass = [i * b / 64 * cpi / (SIMDS * c) for i, b, c in zip(ipb, bf, cyc)]
         tot_cyc = sum(cyc)
-        out["frac_at_held_clock"] = sum(i * b / 64 for i, b in zip(ipb, bf)) * VALU_CYCLES_PER_WAVE_INSTR / (SIMDS * tot_cyc)
+        out["frac_of_peak_at_held_clock_per_pass"] = per_pass
+        out["frac_of_peak_at_held_clock"] = sum(i * b / 64 for i, b in zip(ipb, bf)) * cpi / (SIMDS * tot_cyc)
+        out["kernel_cycles_per_wave_butterfly_per_simd"] = [SIMDS * c / (b / 64) for b, c in zip(bf, cyc)]
         # the clock THIS run held, if a launch takes the same number of cycles as under the profiler
         out["clock_this_run_GHz_estimate"] = [c / (t * 1e6) for c, t in zip(cyc, per_pass_ms)]
         if issue_model:
-            wcyc = [weighted_issue_cycles(m, i, issue_model["costs"], issue_model.get("overhead_cycles", 4.0))
+            wcyc = [weighted_issue_cycles(m, i, issue_model["costs"], issue_model.get("overhead_cycles", cpi))
                     for m, i in zip(issue_model["streams"], ipb)]
-            per_pass = [w * b / 64 / (SIMDS * c) for w, b, c in zip(wcyc, bf, cyc)]
-            out["issue_cycles_per_butterfly_weighted"] = wcyc
-            out["frac_at_held_clock_weighted_per_pass"] = per_pass
-            out["frac_at_held_clock_weighted"] = sum(w * b / 64 for w, b in zip(wcyc, bf)) / (SIMDS * tot_cyc)
-            out["issue_model"] = {"class_cycles": issue_model["costs"], "stream_mix": [m["mix"] for m in issue_model["streams"]],
-                                  "overhead_cycles": issue_model.get("overhead_cycles", 4.0), "source": issue_model.get("source"),
-                                  "measured_stream_cycles_per_butterfly": issue_model.get("measured_stream_cycles")}
-            out["saturated"] = bool(out["frac_at_held_clock_weighted"] >= 0.97)
-            out["verdict"] = ("vector-ALU issue capacity is %.0f %% used at the held clock: saturated, an instruction saved returns as time"
-                              % (100 * out["frac_at_held_clock_weighted"]) if out["saturated"] else
-                              "vector-ALU issue capacity is %.0f %% used at the held clock: the rest is issue stalls (SQ_WAIT_INST_ANY %s of "
-                              "wave-cycles in the counter run: dependent carry chains and LDS / memory waits with 3.7 waves per SIMD)"
-                              % (100 * out["frac_at_held_clock_weighted"],
-                                 "/".join("%.2f" % e[1].get("wave_issue_stall_frac", float("nan")) for e in sq_entries)))
+            out["issue_cost_at_kernel_occupancy"] = {
+                "waves_per_simd_priced": issue_model.get("waves_per_simd"),
+                "class_cycles": issue_model["costs"], "stream_mix": [m["mix"] for m in issue_model["streams"]],
+                "overhead_cycles": issue_model.get("overhead_cycles", cpi), "source": issue_model.get("source"),
+                "measured_stream_cycles_per_butterfly": issue_model.get("measured_stream_cycles"),
+                "cycles_per_butterfly": wcyc,
+                "frac_of_kernel_cycles_per_pass": [w * b / 64 / (SIMDS * c) for w, b, c in zip(wcyc, bf, cyc)],
+                "frac_of_kernel_cycles": sum(w * b / 64 for w, b in zip(wcyc, bf)) / (SIMDS * tot_cyc),
+                "what": "the share of the kernels' cycles that the VALU instructions account for when each is priced at the issue "
+                        "cost measured at this occupancy; the remainder is LDS exchange, waits on memory and barriers",
+            }
+        out["saturated"] = bool(out["frac_of_peak_at_held_clock"] >= 0.9)
+        wv = "/".join("%.1f" % w for w in waves) if all(w for w in waves) else "~4"
+        st = "/".join("%.2f" % x for x in stall) if all(x is not None for x in stall) else "n/a"
+        out["verdict"] = ("vector-ALU at %.0f %% of its SIMD-32 peak at the held clock: saturated, an instruction saved returns as time"
+                          % (100 * out["frac_of_peak_at_held_clock"]) if out["saturated"] else
+                          "vector-ALU at %.0f %% of its SIMD-32 peak at the held clock: NOT saturated -- with %s waves per SIMD a wave's own "
+                          "issue interval (6.8 cycles alone, 3.35 at four waves for the streams' VOP3 forms) is what limits, plus LDS "
+                          "exchange and memory waits (SQ_WAIT_INST_ANY %s of wave-cycles in the counter run)"
+                          % (100 * out["frac_of_peak_at_held_clock"], wv, st))
     return out
 
 
+def decide_bound(pass_frac_of_copy, valu_frac_of_peak, waves=None):
+    """roofline.bound from the run's own numbers: "hbm" when every pass streams at >= 0.9 of the same-run device copy, "valu" when
+    the vector ALU is at >= 0.9 of its SIMD-32 peak, otherwise neither roofline is saturated and the label says what the counters
+    show instead.  Returns (bound, detail).  Pure arithmetic (CPU unit test)."""
+    hb = min(pass_frac_of_copy) if pass_frac_of_copy else None
+    if hb is not None and hb >= 0.9:
+        return "hbm", "every pass streams at >= %.2f of the same-run device copy" % hb
+    if valu_frac_of_peak is not None and valu_frac_of_peak >= 0.9:
+        return "valu", "vector ALU at %.2f of its SIMD-32 peak at the held clock" % valu_frac_of_peak
+    w = ("%.1f" % (sum(waves) / len(waves))) if waves and all(waves) else "~4"
+    return ("issue-latency", "neither roofline is saturated: passes stream at %s of the device copy, vector ALU at %s of its SIMD-32 "
+            "peak; what binds is per-wave issue latency at %s waves per SIMD under the board power cap"
+            % ("%.2f" % hb if hb is not None else "n/a", "%.2f" % valu_frac_of_peak if valu_frac_of_peak is not None else "n/a (no counters "
+               "for these sources)", w))
+
+
 def load_issue_model(passes, src_hash, waves_per_simd=4):
-    """The weighted VALU model's inputs, or (None, reason): profiles/<round>_valu_issue_cost.json (measured on the GPU box by
-    tools/valu_issue_cost) and profiles/<round>_valu_mix.json (tools/valu_mix.py, stamped with the kernel-source hash)."""
+    """Inputs of roofline.valu.issue_cost_at_kernel_occupancy, or (None, reason): the newest profiles/rNN_valu_issue_cost.json
+    (measured on the GPU box by tools/valu_issue_cost) and profiles/rNN_valu_mix.json (tools/valu_mix.py, stamped with the
+    kernel-source hash)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
-    cost_path = os.path.join(ROOT, "profiles", "%s_valu_issue_cost.json" % PROFILE_ROUND)
-    if not os.path.exists(cost_path):
-        return None, "profiles/%s_valu_issue_cost.json absent" % PROFILE_ROUND
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_valu_issue_cost.json")))  # a property of the chip, not
+    if not found:                                                                                  # of the sources: newest wins
+        return None, "profiles/rNN_valu_issue_cost.json absent"
+    cost_path = found[-1]
     mix, why = tagged_profile("valu_mix", src_hash)
     if mix is None:
         return None, why
@@ -305,8 +357,9 @@ def load_issue_model(passes, src_hash, waves_per_simd=4):
     # first pass: per-lane twiddles (VGPRs); column passes: wave-uniform twiddles (SGPRs)
     streams = [mix["streams"]["gl_fwd_v" if kind == "contig" else "gl_fwd_s"] for kind, _, _ in passes]
     meas = {k: v["cycles_per_butterfly"].get(str(waves_per_simd)) for k, v in ic.get("streams", {}).items()}
-    return {"costs": costs, "streams": streams, "overhead_cycles": costs.get("other", 4.0), "measured_stream_cycles": meas,
-            "source": "profiles/%s_valu_issue_cost.json at %d waves per SIMD + %s" % (PROFILE_ROUND, waves_per_simd, why)}, None
+    return {"costs": costs, "streams": streams, "overhead_cycles": costs.get("other", VALU_PEAK_CYCLES_PER_WAVE_INSTR),
+            "measured_stream_cycles": meas, "waves_per_simd": waves_per_simd,
+            "source": "%s at %d waves per SIMD + %s" % (os.path.relpath(cost_path, ROOT), waves_per_simd, why)}, None
 
 
 # ---- verification of a shard: every rank, every device --------------------------------------------------------------------
@@ -379,24 +432,38 @@ def reduce_verdicts(dist, torch, dev, world, rank, flags, ident):
     return [bool(v) for v in t.tolist()], recs
 
 
-def verdict_fields(reduced, recs, world_seen):
-    """The line's verification block and the process exit code (non-zero when ANY rank failed either check)."""
-    ok = all(reduced)
+def verdict_fields(reduced, recs, world_seen, one_device_ok=False):
+    """The line's verification block and the process exit code (non-zero when ANY rank failed either check, or when the ranks
+    of a multi-rank job are not provably on `world_seen` distinct devices: a job whose ranks all landed on one GPU would
+    otherwise print a green aggregate of one GPU's time-sliced work.  one_device_ok (the NTT_BENCH_ONE_DEVICE=1 rehearsal on a
+    one-GPU box) waives the distinctness rule and says so in the line)."""
     ids = [r.get("pci_bus_id") or r.get("uuid") for r in recs]
+    distinct = len(set(i for i in ids if i)) if any(ids) else None
+    if world_seen <= 1 or one_device_ok:
+        placed = True
+    else:
+        placed = distinct is not None and all(ids) and distinct == world_seen and len(recs) == world_seen
+    ok = all(reduced) and placed
     return {"all_ranks_verified": ok, "world_size_seen": int(world_seen),
             "verification": {"round_trip_identical_all": reduced[0], "coefficient_sum_invariant_all": reduced[1],
+                             "ranks_on_distinct_devices": bool(placed) if not one_device_ok else None,
+                             "distinctness_waived_one_device_rehearsal": bool(one_device_ok),
                              "what": "every rank: inverse(forward(x)) == x over its whole shard (torch.equal) and out[b][0] == "
-                                     "sum(a[b][:]) mod p on sampled rows; flags reduced with all_reduce(MIN)"},
-            "distinct_devices": len(set(i for i in ids if i)) if any(ids) else None,
+                                     "sum(a[b][:]) mod p on sampled rows; flags reduced with all_reduce(MIN); a multi-rank line is "
+                                     "verified only when every rank reports a device identity and all of them differ"},
+            "distinct_devices": distinct,
             "ranks": recs}, (0 if ok else 1)
 
 
 def self_launch(args, argv):
-    """`python bench.py --gpus N` without a launcher: the parent -- before anything touches the GPU -- starts the N ranks
-    as `python -m torch.distributed.run ... bench.py <same arguments>` in a fresh child process, relays the child's
-    output (rank 0's ONE JSON line) and exit code.  The torchrun form keeps working: with WORLD_SIZE set this is never reached."""
-    import socket
+    """`python bench.py --gpus N` without a launcher: the parent -- before anything touches the GPU -- starts the N ranks itself,
+    one child process per rank with RANK / LOCAL_RANK / WORLD_SIZE in its environment and a FILE rendezvous in a fresh temporary
+    directory (--rdzv-file: torch.distributed's FileStore; RCCL's own bootstrap sockets bind port 0 themselves).  No TCP port is
+    probed, released and handed over, so there is nothing to collide on and nothing to retry: a failed launch is reported with
+    its exit code, as the reference reports a failed run (src/test.cpp:162-166).  Rank 0's ONE JSON line is relayed.
+    The torchrun form keeps working: with WORLD_SIZE set this function is never reached."""
     import subprocess
+    import tempfile
 
     rehearsal = os.environ.get("NTT_BENCH_ONE_DEVICE") == "1"
     if not rehearsal:
@@ -408,24 +475,47 @@ def self_launch(args, argv):
                              "(NTT_BENCH_ONE_DEVICE=1 NTT_BENCH_BACKEND=gloo rehearses the launch path on one device)\n"
                              % (args.gpus, have))
             return 2
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    proc = None
-    for _ in range(4):
-        # a free port is probed, released and handed to the launcher: another process can take it in between (EADDRINUSE) --
-        # then, and only then, the launch is repeated on a new port
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-        collided = proc.returncode != 0 and ("EADDRINUSE" in proc.stderr or "address already in use" in proc.stderr.lower())
-        if not collided:
-            break
-    sys.stderr.write(proc.stderr)
-    sys.stdout.write(proc.stdout)
+    base = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("MASTER_ADDR", "MASTER_PORT"):
+        base.pop(k, None)
+    with tempfile.TemporaryDirectory(prefix="ntt_rdzv_") as tmp:
+        rdzv = os.path.join(tmp, "store")
+        procs, logs = [], []
+        for r in range(args.gpus):  # every rank's output goes to a file of its own: no pipe can fill up while another rank is awaited
+            env = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus))
+            fo, fe = open(os.path.join(tmp, "out%d" % r), "w+"), open(os.path.join(tmp, "err%d" % r), "w+")
+            logs.append((fo, fe))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--rdzv-file", rdzv], env=env,
+                                          stdout=fo, stderr=fe, text=True))
+        # a rank that dies (before or after the rendezvous) would leave the others waiting on it: the first non-zero exit ends
+        # the job -- the exact children started above are terminated, nothing is restarted
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                for p in procs:
+                    try:
+                        p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                break
+            time.sleep(0.05)
+        codes = [p.wait() for p in procs]
+        outs = []
+        for fo, fe in logs:
+            fo.seek(0)
+            fe.seek(0)
+            outs.append((fo.read(), fe.read()))
+            fo.close()
+            fe.close()
+    for r, (_, err) in enumerate(outs):
+        if err and (codes[r] != 0 or r == 0):
+            sys.stderr.write(err if r == 0 else "[rank %d] %s" % (r, err))
+    sys.stdout.write(outs[0][0] or "")
     sys.stdout.flush()
-    return proc.returncode
+    bad = [c for c in codes if c > 0] or [1 for c in codes if c != 0]  # a rank's own exit code before "terminated by the parent"
+    return bad[0] if bad else 0
 
 
 def config_name(logn, batch, world):
@@ -468,7 +558,8 @@ PREWARM = 8  # untimed, before the W warm-up steps: first touches of 4 GiB (TLB)
 def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
     """Rank 0 / device 0 only, AFTER the timed region and the verification: step-time distribution, the roofline object
     (per-pass hipEvents, device copy, VALU floor, counters quoted from profiles/ when their hash matches), the CPU baseline
-    (N = 1 only) and config 3's inverse leg.  Overwrites y."""
+    (N = 1 only), config 3's inverse leg and BASELINE configs 2 and 4 (N = 1, default shape).  Overwrites y.  Returns an exit
+    code: non-zero when one of the extra configurations computed a wrong result."""
     import numpy as np
 
     from ntt_aie_amd import _lib
@@ -528,30 +619,38 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
                 model, model_why = load_issue_model(passes, src_hash)
                 valu = valu_roofline(ent, passes, [float(v) for v in per_pass], batch, logn, issue_model=model)
                 if model is None:
-                    valu["issue_model"] = None
-                    valu["issue_model_source"] = "weighted figure not computed: " + model_why
+                    valu["issue_cost_at_kernel_occupancy"] = None
+                    valu["issue_cost_source"] = "not computed: " + model_why
             else:
                 valu_src += "; not quoted: " + why
     step_s = out["ms_per_step"] * 1e-3
+    pass_of_copy = [alg_bytes / (float(v) * 1e-3) / 1e9 / copy["GBs"] for v in per_pass]
+    vfrac = valu.get("frac_of_peak_at_held_clock") if valu else None
+    bound, bound_detail = decide_bound(pass_of_copy, vfrac, valu.get("mean_waves_per_simd") if valu else None)
+    # what this pass count can reach on THIS device: every trip at the rate a plain copy of the same bytes achieves here
+    practical_ms = len(passes) * copy["ms"]
     out["roofline"] = {
-        # The contract's figure: algorithmic HBM bytes / kernel time against the 8 TB/s spec peak (achieved, peak, unit, frac).
-        # `bound` names the unit that actually binds this integer kernel: the vector ALU, whose own roofline
-        # is the `valu` object; `frac_ceiling` is what `frac` could reach at most with this pass count.
-        "bound": "valu",
-        "bound_note": "achieved/peak/frac are the HBM roofline SURVEY 8(d) prescribes (algorithmic bytes over the spec peak); the "
-                      "binding unit is the vector ALU under the 1400 W board power cap (roofline.valu: instructions per "
-                      "butterfly against 1024 SIMDs x clock / measured issue cycles; profiles/%s_power_probe.txt for the clock the cap "
-                      "allows) -- each pass streams at ~0.87 of the device-copy rate, so HBM is the second constraint, not the first"
-                      % PROFILE_ROUND,
+        # The contract's figure: algorithmic HBM bytes / kernel time against the 8 TB/s spec peak (achieved, peak, unit, frac);
+        # `roofline_of_fields` says which roofline those four numbers are.  `bound` is decided from the run's numbers
+        # (decide_bound): "hbm" / "valu" only when that unit is at >= 0.9 of what it can do, otherwise what the counters show.
+        "bound": bound, "bound_detail": bound_detail, "roofline_of_fields": "hbm",
+        "bound_note": "achieved/peak/frac are the HBM roofline SURVEY 8(d) prescribes (algorithmic bytes over the spec peak); "
+                      "frac_ceiling is what frac could reach at most with this pass count, frac_of_practical_hbm how close the step is "
+                      "to %d trips at the same-run device-copy rate; roofline.valu is the vector-ALU roofline on the SIMD-32 peak "
+                      "(2 cycles per wave64 instruction).  The board power cap (1400 W) sets the clock the kernels hold."
+                      % len(passes),
         "frac_ceiling": 1.0 / len(passes),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        # the same bytes over the step time the line's own `value` is made of (launch gaps included).  A step cannot be shorter
-        # than its kernels, so frac_step is capped at frac; the two are measured seconds apart, and when the uncapped quotient
-        # (frac_step_uncapped) comes out above frac the difference is the clock the chip held in each phase, not a faster step
-        "frac_step": min(alg_bytes / step_s / 1e9, achieved) / HBM_PEAK_GBS,
-        "frac_step_uncapped": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+        # the same bytes over the step time the line's own `value` is made of (launch gaps included), NOT clamped: a step cannot be
+        # shorter than its kernels, so frac_step <= frac up to the clock the chip held in each phase (the two are measured seconds
+        # apart); the GPU contract test asserts frac_step <= 1.03 x frac instead of hiding a violation behind a min()
+        "frac_step": alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
         "achieved_step": alg_bytes / step_s / 1e9,
+        "practical_hbm_floor_ms": practical_ms,
+        "frac_of_practical_hbm": practical_ms / (step_s * 1e3),
+        "frac_of_practical_hbm_what": "%d trips x the time a device copy of the same algorithmic bytes takes in this run (%.3f ms each) / "
+                                      "ms_per_step" % (len(passes), copy["ms"]),
         "traffic": traffic, "traffic_source": traffic_src,
         "definition": "algorithmic bytes of one forward transform (2*N*8 B) x batch / summed duration of its "
                       "%d pass kernels (hipEvents on the launch stream); frac_step divides by ms_per_step of the timed region instead "
@@ -566,23 +665,19 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
         "pass_stream_frac": [alg_bytes / (float(v) * 1e-3) / 1e9 / HBM_PEAK_GBS for v in per_pass],
         # the same bytes through a plain copy, same process, same buffers: the achievable rate beside the spec peak
         "device_copy": copy, "frac_of_device_copy": achieved / copy["GBs"],
-        "pass_stream_frac_of_device_copy": [alg_bytes / (float(v) * 1e-3) / 1e9 / copy["GBs"] for v in per_pass],
-        # the binding unit of this integer workload is the vector ALU: floor = the same kernels, loads from L2, no stores
+        "pass_stream_frac_of_device_copy": pass_of_copy,
+        # floor = the same kernels, loads from L2, no stores: what the butterflies + exchanges cost with no HBM traffic
         "valu_floor_pass_ms": floor,
         "valu_floor_frac_of_pass": ([f / float(v) for f, v in zip(floor, per_pass)] if floor else None),
         "valu_floor_source": floor_src,
         "valu": valu, "valu_source": valu_src,
     }
     if world == 1 and not args.no_cpu_baseline:
-        def rows_fn(k):
-            # rows [0, k) of the job's input: the head of the resident buffer, continued by the same generator beyond the batch
-            head = x[:min(k, batch)].cpu().numpy().view(np.uint64)
-            if k <= batch:
-                return np.ascontiguousarray(head)
-            more = synth_batch(torch, k - batch, n, x.device, first_row=batch).cpu().numpy().view(np.uint64)
-            return np.concatenate([head, more])
+        def rows_fn(k):  # rows [0, k) of the resident input buffer, k <= batch (cpu_baseline caps its sample there)
+            assert k <= batch
+            return np.ascontiguousarray(x[:k].cpu().numpy().view(np.uint64))
 
-        out["cpu_baseline"] = cpu_baseline(logn, p, table, rows_fn, threads=args.cpu_threads or None)
+        out["cpu_baseline"] = cpu_baseline(logn, p, table, rows_fn, batch, threads=args.cpu_threads or None)
     # BASELINE config 3 is forward + inverse: the inverse transform of the same batch, outside the timed region above
     # (scaled by N^-1, natural order in and out), one event pair per step; measured LAST so that nothing it allocates or heats
     # perturbs the roofline measurements above
@@ -602,6 +697,221 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
                           "vs_forward_median": inv_ms[len(inv_ms) // 2] / out["step_ms_median"],
                           "round_trip_identical": bool(torch.equal(x2, x))}
         del x2
+    # BASELINE configs 2 and 4 in the same driver-run line (one GPU, default shape only; --no-configs for counter collections,
+    # whose per-kernel means must see the headline's launches alone).  A config whose result is WRONG turns the exit code red.
+    code = 0
+    if world == 1 and headline and not args.no_configs:
+        out["configs"] = extra_configs(torch, stream, src_hash, steps=max(5, min(args.steps, 20)))
+        out["configs_all_verified"] = all(e.get("verified") for e in out["configs"])
+        if any(not e.get("verified") and "error" not in e for e in out["configs"]):
+            code = 1
+    return code
+
+
+# ---- the other single-GPU BASELINE configurations, in the same driver-run line ---------------------------------------------
+# The reference prints every timing it publishes from the one program the user runs (src/test.cpp:157-175).  After the headline's
+# timed region and verification, rank 0 of a one-GPU default run measures BASELINE config 2 (N = 2^12, 32-bit prime, batch 1024,
+# forward) and config 4 (N = 2^20 negacyclic product, Goldilocks, batch 512) for a few steps each and verifies each without the
+# oracle; config 3's inverse leg is the `inverse` key.  tools/configs.py holds the shapes and their algorithmic bytes.
+def synth_u32(torch, batch, n, p, device, seed=SEED, first_row=0):
+    """[batch][n] residues of a 32-bit modulus as int32 bit patterns: a[b][i] = splitmix64(seed + (first_row + b)*n + i) mod p.
+    The unsigned 64-bit word u = hi*2^32 + lo is reduced as ((hi mod p) * (2^32 mod p) + lo) mod p, which fits int64 when
+    (p - 1) * (2^32 mod p) + 2^32 < 2^63 (asserted)."""
+    r32 = (1 << 32) % p
+    assert p < (1 << 32) and (p - 1) * r32 + (1 << 32) < (1 << 63), "modulus outside the generator's int64 window"
+    out = torch.empty((batch, n), dtype=torch.int32, device=device)
+    rows = max(1, (1 << 24) // n)
+    for r0 in range(0, batch, rows):
+        r1 = min(batch, r0 + rows)
+        z = splitmix64_words(torch, seed + (first_row + r0) * n, (r1 - r0) * n, device)
+        hi, lo = (z >> 32) & 0xFFFFFFFF, z & 0xFFFFFFFF
+        v = ((hi % p) * r32 + lo) % p
+        out[r0:r1] = torch.where(v >= (1 << 31), v - (1 << 32), v).to(torch.int32).view(r1 - r0, n)
+    return out
+
+
+def rowsum_mod_p_u32(rows, p):
+    """[sum(row) mod p] for uint32 rows (N <= 2^28 words of < 2^32 sum below 2^60)."""
+    import numpy as np
+
+    rows = np.ascontiguousarray(rows).view(np.uint32)
+    return [int(v) % p for v in rows.sum(axis=1, dtype=np.uint64)]
+
+
+def poly_eval_mod(coeffs, r, p):
+    """sum(coeffs[i] * r^i) mod p by Horner's rule on Python integers (0.2-0.3 s per 2^20 coefficients)."""
+    acc = 0
+    for v in coeffs[::-1].tolist():
+        acc = (acc * r + v) % p
+    return acc
+
+
+def events_ms(torch, fn, stream, steps, warmup):
+    """median ms of `steps` calls of fn, one hipEvent pair per call on `stream`, and the ms per call of the same calls issued
+    back to back inside one pair (what a resident pipeline of these operations takes)."""
+    for _ in range(warmup):
+        fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for e0, e1 in evs:
+        e0.record(stream)
+        fn()
+        e1.record(stream)
+    b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b0.record(stream)
+    for _ in range(steps):
+        fn()
+    b1.record(stream)
+    stream.synchronize()
+    each = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    return each[len(each) // 2], b0.elapsed_time(b1) / steps
+
+
+def config_roofline(cfg_key, c, op_ms, copy_ms, passes, src_hash):
+    """bench.py's roofline keys for one BASELINE configuration (tools/configs.py): achieved = algorithmic bytes of one operation /
+    time per operation; traffic and the vector-ALU fraction are quoted from profiles/rNN_<cfg>_pmc_traffic.json /
+    _sq_counters.json (tools/collect_profiles.sh) only when their kernel-source hash equals this tree's."""
+    from configs import algorithmic_bytes
+    from hw import valu_frac_of_peak
+
+    alg = float(algorithmic_bytes(c))
+    achieved = alg / (op_ms * 1e-3) / 1e9
+    pmc, pmc_src = tagged_profile("%s_pmc_traffic" % cfg_key, src_hash)
+    sq, sq_src = tagged_profile("%s_sq_counters" % cfg_key, src_hash)
+    traffic = pmc["per_op"]["hbm_bytes"] if pmc else None
+    valu = None
+    if sq and sq["per_op"].get("kernel_cycles"):
+        po = sq["per_op"]
+        valu = {"instr_per_butterfly": po["valu_instr_per_butterfly"],
+                "frac_of_peak_at_held_clock": valu_frac_of_peak(po["valu_instr"], po["kernel_cycles"]),
+                "mean_waves_per_simd": [k.get("mean_waves_per_simd") for k in sq["kernels"].values()],
+                "held_clock_GHz": [k.get("held_clock_GHz") for k in sq["kernels"].values()],
+                "kernels": [k["short"] for k in sq["kernels"].values()],
+                "what": "SQ_INSTS_VALU per operation x %g cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 per operation): clock-free, on the "
+                        "SIMD-32 peak" % VALU_PEAK_CYCLES_PER_WAVE_INSTR}
+    # physical trips through HBM on the convention the algorithmic bytes use: a transform moves 2N words per pass; the product's
+    # fused schedule (inverse column passes of a and b 4N, fused middle 3N, forward column pass 2N) moves exactly the 9N it is priced on
+    ceiling = 1.0 if c["op"] == "polymul" else 1.0 / max(1, passes)
+    copy_gbs = alg / (copy_ms * 1e-3) / 1e9 if copy_ms else None
+    of_copy = (achieved / ceiling / copy_gbs) if copy_gbs else None
+    if op_ms < 0.05 and not (of_copy and of_copy >= 0.9):
+        bound, why = "latency", ("one generation of workgroups: a %.1f us launch is a workgroup's own load -> butterflies -> store chain, "
+                                 "not a throughput limit" % (op_ms * 1e3))
+    else:
+        bound, why = decide_bound([of_copy] if of_copy else None, valu["frac_of_peak_at_held_clock"] if valu else None,
+                                  [w for w in valu["mean_waves_per_simd"] if w] if valu else None)
+    return {"bound": bound, "bound_detail": why, "roofline_of_fields": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "frac_ceiling": ceiling,
+            "traffic": traffic, "traffic_ratio_to_algorithmic": (traffic / alg if traffic else None), "traffic_source": pmc_src,
+            "valu": valu, "valu_source": sq_src,
+            "algorithmic_bytes_per_op": alg, "device_copy_same_bytes_GBs": copy_gbs, "frac_of_device_copy": of_copy,
+            "definition": "algorithmic bytes of one operation (SURVEY 8d: 2N words per transform, 9N per product) / hipEvent time per "
+                          "operation (back-to-back operations on the launch stream)"}
+
+
+def run_config(torch, key, stream, src_hash, steps):
+    """One BASELINE configuration end to end on the current device: plan, synthetic resident inputs (the SURVEY 8d generator),
+    warm-up, `steps` timed operations, and an oracle-free verification of the result -- forward: inverse(forward(x)) == x over the
+    whole batch and out[b][0] == sum(a[b][:]) mod p on sampled rows; product: c(r) == a(r) * b(r) mod p at a root r of x^N + 1 on
+    sampled rows (Horner on Python integers: true for the negacyclic product and for nothing else) and, over the whole batch,
+    InvU(c) == InvU(a) . InvU(b) word by word through the plain inverse passes and the pointwise kernel (other kernels than the
+    fused product path ran)."""
+    import numpy as np
+
+    from configs import CONFIGS, algorithmic_bytes, butterflies
+    from ntt_aie_amd import NTTPlan
+
+    c = CONFIGS[key]
+    logn, p, wb, batch = c["logn"], c["p"], c["wb"], c["batch"]
+    n = 1 << logn
+    dev = torch.device("cuda", torch.cuda.current_device())
+    plan = NTTPlan(logn, p, wb, dev.index)
+    plan.set_twiddles(plan.make_table(c["kind"], c["g"]))
+
+    def synth(first_row):
+        return synth_batch(torch, batch, n, dev, first_row=first_row) if wb == 8 else synth_u32(torch, batch, n, p, dev, first_row=first_row)
+
+    base_row = {"cfg2": 1 << 20, "cfg2_sat": 1 << 21, "cfg4": 1 << 22}.get(key, 1 << 23)  # rows the headline's batch never uses
+    entry = {"name": c["name"], "key": key, "baseline_config": {"cfg2": 2, "cfg4": 4}.get(key), "logn": logn, "word_bytes": wb,
+             "modulus": p, "batch": batch, "op": c["op"], "steps": steps, "data": "synthetic (splitmix64 mod p, rows %d.. of the job's generator)" % base_row}
+    words = algorithmic_bytes(c) // 2 // wb
+    if c["op"] == "forward":
+        x = synth(base_row)
+        y = torch.empty_like(x)
+        med, b2b = events_ms(torch, lambda: plan.forward(x, y, stream=stream), stream, steps, 8)
+        passes = plan.passes_for(batch)
+        back = plan.inverse(y, stream=stream)
+        stream.synchronize()
+        rt = bool(torch.equal(back, x))
+        rows = sorted(set(int(r) for r in np.linspace(0, batch - 1, min(16, batch))))
+        idx = torch.tensor(rows, device=dev)
+        xs = x.index_select(0, idx).cpu().numpy()
+        y0 = y[:, 0].index_select(0, idx).cpu().numpy()
+        if wb == 8:
+            got, want = [int(v) for v in y0.view(np.uint64)], rowsum_mod_p(xs, p)
+        else:
+            got, want = [int(v) for v in y0.view(np.uint32)], rowsum_mod_p_u32(xs, p)
+        sums = got == want and all(v < p for v in got)
+        entry.update({"verified": bool(rt and sums),
+                      "verification": {"round_trip_identical": rt, "coefficient_sum_invariant": bool(sums), "rows_sampled": len(rows)},
+                      "hbm_passes": len(passes), "pass_stages": [st for _, _, st in passes]})
+        del back
+        npass = len(passes)
+    else:
+        a0, b0 = synth(base_row), synth(base_row + batch)
+        a, b = a0.clone(), b0.clone()
+        cbuf = torch.empty_like(a0)
+        plan.polymul_negacyclic(a, b, cbuf, stream=stream)  # the verified product: fresh operands (the entry point overwrites them)
+        stream.synchronize()
+        r = pow(c["g"], (p - 1) // (2 * n), p)
+        assert pow(r, n, p) == p - 1, "r must be a root of x^N + 1"
+        rows = sorted(set(int(v) for v in np.linspace(0, batch - 1, 2)))
+        ev = True
+        for rr in rows:
+            av, bv, cv = (t[rr].cpu().numpy().view(np.uint64) for t in (a0, b0, cbuf))
+            ev = ev and bool(cv.max() < p) and poly_eval_mod(cv, r, p) == poly_eval_mod(av, r, p) * poly_eval_mod(bv, r, p) % p
+        # whole batch: InvU(InvU(a) . InvU(b) . N^-1 -> Fwd) == InvU(a) . InvU(b); the unscaled inverse of a forward is N x identity
+        ia = plan.inverse(a0, a, scale=False, stream=stream)   # a, b: scratch from here on
+        ib = plan.inverse(b0, b, scale=False, stream=stream)
+        prod = plan.pointwise_mul(ia, ib, ia, stream=stream)
+        ic = plan.inverse(cbuf, ib, scale=False, stream=stream)
+        stream.synchronize()
+        dom = bool(torch.equal(prod, ic))
+        # timed: operands in separate buffers, overwritten by every call (transform-domain words of the previous call: canonical residues)
+        med, b2b = events_ms(torch, lambda: plan.polymul_negacyclic(a, b, cbuf, stream=stream), stream, steps, 2)
+        entry.update({"verified": bool(ev and dom),
+                      "verification": {"evaluation_at_root_of_xN_plus_1": ev, "rows_evaluated": len(rows),
+                                       "transform_domain_identity_whole_batch": dom,
+                                       "what": "c(r) == a(r) b(r) mod p, r = %d^((p-1)/2N) (Horner, Python integers) on %d rows; InvU(c) == "
+                                               "InvU(a) . InvU(b) over all %d products through the plain passes + pointwise kernel" % (c["g"], len(rows), batch)},
+                      "hbm_passes": plan.hbm_passes})
+        npass = plan.hbm_passes
+        del a0, b0, a, b, cbuf
+    op_ms = min(med, b2b)
+    src = torch.empty(words, dtype=torch.int64 if wb == 8 else torch.int32, device=dev)
+    dst = torch.empty_like(src)
+    _, copy_ms = events_ms(torch, lambda: dst.copy_(src), stream, 10, 3)
+    del src, dst
+    unit = "products/s" if c["op"] == "polymul" else "NTT/s"
+    entry.update({"ms": op_ms, "ms_median_single": med, "ms_back_to_back": b2b, "value": batch / (op_ms * 1e-3), "unit": unit,
+                  "butterflies_per_s": butterflies(c) / (op_ms * 1e-3),
+                  "roofline": config_roofline(key, c, op_ms, copy_ms, npass, src_hash)})
+    plan.close()
+    return entry
+
+
+def extra_configs(torch, stream, src_hash, steps=10):
+    """[entry per config] and whether every entry that ran verified; an entry that could not run (exception) is reported with
+    its error and counts as NOT verified -- it never stops the headline line from being printed."""
+    out = []
+    for key in ("cfg2", "cfg4"):
+        try:
+            with torch.cuda.stream(stream):
+                out.append(run_config(torch, key, stream, src_hash, steps))
+        except Exception as e:  # reported in the line; the headline's own numbers stand
+            sys.stderr.write("bench.py: config %s failed: %r\n" % (key, e))
+            out.append({"key": key, "verified": False, "error": repr(e)})
+        torch.cuda.empty_cache()
+    return out
 
 
 def run_single_process(args):
@@ -675,10 +985,10 @@ def run_single_process(args):
             v = verify_shard(torch, pl, x, y, p, st)
         flags = [flags[0] and v["round_trip_identical"], flags[1] and v["coefficient_sum_invariant"]]
         recs.append(dict(device_identity(torch, d), rank=i, ms_per_step=dev_ms[i], **v))
-    fields, code = verdict_fields(flags, recs, ndev)
+    fields, code = verdict_fields(flags, recs, ndev, one_device_ok=rehearsal)
     out.update(fields)
     with torch.cuda.device(devs[0]), torch.cuda.stream(streams[0]):  # torch's own kernels (the device copy) on the launch stream too
-        rank0_extras(torch, args, plan0, table, xs[0], ys[0], streams[0], passes, out, ndev)
+        code = max(code, rank0_extras(torch, args, plan0, table, xs[0], ys[0], streams[0], passes, out, ndev))
     print(json.dumps(out), flush=True)
     return code
 
@@ -696,10 +1006,15 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's multi-core leg (default: every core of the affinity mask)")
     ap.add_argument("--no-valu-floor", action="store_true",
                     help="skip the VALU-floor leg (its launches carry the same kernel names: keep them out of a rocprofv3 --stats run)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip BASELINE configs 2 and 4 (counter collections: the headline's launches alone in the profile)")
     ap.add_argument("--no-inverse", action="store_true",
                     help="skip the inverse-transform leg (counter collection: only forward kernels in the profile)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the twiddle broadcast path")
+    ap.add_argument("--rdzv-file", default=None,
+                    help="rendezvous through this file (torch.distributed FileStore) instead of MASTER_ADDR / MASTER_PORT: no TCP "
+                         "port to agree on; what `python bench.py --gpus N` uses for the ranks it starts itself")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -735,12 +1050,22 @@ def main():
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # a launcher (torchrun, the driver) supplies MASTER_ADDR / MASTER_PORT; without one the rendezvous is a file
+        # (--rdzv-file; a one-rank --force-dist run without either makes its own temporary one): no port is ever guessed
+        kw = {}
+        if args.rdzv_file or "MASTER_PORT" not in os.environ:
+            import tempfile
+
+            path = args.rdzv_file or os.path.join(tempfile.mkdtemp(prefix="ntt_rdzv_"), "store")
+            if world > 1 and not args.rdzv_file:
+                raise SystemExit("multi-rank run without MASTER_ADDR/MASTER_PORT or --rdzv-file: nothing to rendezvous on")
+            kw["init_method"] = "file://" + path
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, **kw)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     from ntt_aie_amd.dist import ShardedNTT
 
@@ -780,7 +1105,8 @@ def main():
         v["round_trip_identical"] = False
     ident = dict(device_identity(torch, local_rank), rank=rank, ms_per_step=own / args.steps * 1e3, **v)
     reduced, recs = reduce_verdicts(dist, torch, dev, world, rank, [v["round_trip_identical"], v["coefficient_sum_invariant"]], ident)
-    fields, code = verdict_fields(reduced, recs, dist.get_world_size() if use_dist else 1)
+    fields, code = verdict_fields(reduced, recs, dist.get_world_size() if use_dist else 1,
+                                  one_device_ok=os.environ.get("NTT_BENCH_ONE_DEVICE") == "1")
 
     total_ntt = batch * world * args.steps
     value = total_ntt / elapsed
@@ -790,7 +1116,7 @@ def main():
     out.update(fields)
 
     if rank == 0:
-        rank0_extras(torch, args, plan, eng.table, x, y, stream, passes, out, world)
+        code = max(code, rank0_extras(torch, args, plan, eng.table, x, y, stream, passes, out, world))
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -49,73 +49,48 @@ def oracle():
     return oracle_py
 
 
-# ---- rendezvous ports ---------------------------------------------------------------------------------------------------
-# A test that starts a torch.distributed job picks a free TCP port, closes the probe socket and hands the number to the job: between
-# the two another process (a rank of the previous test that is still shutting down) can take it, and the job dies with EADDRINUSE.
-# Every such test goes through run_with_fresh_port(): the job is started again on a new port when -- and only when -- that is why
-# it failed.
-def free_port() -> int:
-    import socket
+# ---- rendezvous ----------------------------------------------------------------------------------------------------------
+# Every test that starts a torch.distributed job rendezvouses through a FILE in a fresh temporary directory
+# (init_method="file://..."), never through a TCP port: a port that is probed, released and handed to the job can be taken by
+# another process in between (round 4: EADDRINUSE in tests/test_gpu_dist.py), and a retry only hides the next occurrence.  A
+# failed rendezvous is reported, not retried -- as the reference reports a failed launch (src/test.cpp:162-166).
+def spawn_world(worker, world: int, extra_args: tuple = (), timeout: int = 240):
+    """Start `world` processes of worker(rank, world, rdzv_file, queue, *extra_args) (torch.multiprocessing, spawn) and return
+    their queue items sorted by rank.  A worker that fails puts ("FAILED", rank, text) instead of raising."""
+    import tempfile
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def port_collision(text: str) -> bool:
-    return "EADDRINUSE" in text or "address already in use" in text.lower()
-
-
-def run_with_fresh_port(start, attempts: int = 4):
-    """start(port) -> subprocess.CompletedProcess (stdout / stderr captured as text).  Returns the first result that is not a port
-    collision (or the last one)."""
-    out = None
-    for _ in range(attempts):
-        out = start(free_port())
-        if out.returncode == 0 or not port_collision((out.stdout or "") + (out.stderr or "")):
-            return out
-    return out
-
-
-def spawn_world(worker, world: int, extra_args: tuple = (), attempts: int = 4, timeout: int = 180):
-    """Start `world` processes of worker(rank, world, port, queue, *extra_args) (torch.multiprocessing, spawn) and return their
-    queue items sorted.  A worker reports a failed rendezvous by putting ("RENDEZVOUS_FAILED", rank, text) instead of raising;
-    when that text is a port collision the whole world is started again on a fresh port."""
     import torch.multiprocessing as mp
 
-    last = None
-    for _ in range(attempts):
-        ctx = mp.get_context("spawn")
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory(prefix="ntt_rdzv_") as tmp:
         q = ctx.Queue()
-        port = free_port()
-        procs = [ctx.Process(target=worker, args=(r, world, port, q) + tuple(extra_args)) for r in range(world)]
+        rdzv = os.path.join(tmp, "store")
+        procs = [ctx.Process(target=worker, args=(r, world, rdzv, q) + tuple(extra_args)) for r in range(world)]
         for p in procs:
             p.start()
-        items = [q.get(timeout=timeout) for _ in procs]
-        for p in procs:
-            p.join(timeout=60)
-        failed = [i for i in items if isinstance(i, tuple) and i and i[0] == "RENDEZVOUS_FAILED"]
-        if not failed:
-            assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-            return sorted(items, key=lambda i: i[0])
-        last = failed
-        if not any(port_collision(f[2]) for f in failed):
-            break
-    raise AssertionError("rendezvous failed: %r" % (last,))
+        try:
+            items = [q.get(timeout=timeout) for _ in procs]
+        finally:
+            for p in procs:
+                p.join(timeout=60)
+                if p.is_alive():  # the exact children started above
+                    p.terminate()
+    failed = [i for i in items if isinstance(i, tuple) and i and i[0] == "FAILED"]
+    assert not failed, "worker failed: %r" % (failed,)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return sorted(items, key=lambda i: i[0])
 
 
-def init_gloo_or_report(rank: int, world: int, port: int, q) -> bool:
-    """In a spawned worker: gloo process group on 127.0.0.1:port.  False (after reporting to the parent) when the rendezvous failed."""
-    import os
-
+def init_gloo_or_report(rank: int, world: int, rdzv_file: str, q) -> bool:
+    """In a spawned worker: gloo process group over a file rendezvous.  False (after reporting to the parent) when it failed."""
     import torch.distributed as dist
 
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     try:
         from datetime import timedelta
 
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=60))
+        dist.init_process_group("gloo", init_method="file://" + rdzv_file, rank=rank, world_size=world,
+                                timeout=timedelta(seconds=120))
         return True
-    except Exception as e:  # the parent decides whether to start the world again
-        q.put(("RENDEZVOUS_FAILED", rank, repr(e)))
+    except Exception as e:
+        q.put(("FAILED", rank, repr(e)))
         return False

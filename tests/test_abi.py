@@ -110,7 +110,7 @@ def test_tools_and_bench_timed_region_do_not_touch_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import or run anything under oracle/:
     no script under tools/ mentions the oracle modules, and bench.py imports them only inside cpu_baseline()."""
     tools = os.path.join(ROOT, "tools")
-    for dirpath, _, files in os.walk(tools):  # tools/ and tools/archive/
+    for dirpath, _, files in os.walk(tools):
         for f in files:
             if f.endswith((".py", ".sh", ".hip")):
                 text = open(os.path.join(dirpath, f)).read()

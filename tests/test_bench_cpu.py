@@ -1,5 +1,6 @@
-"""bench.py's host logic on the CPU: the per-rank verification reduce (one bad rank turns the whole line red), the
-coefficient-sum invariant's arithmetic, the weighted VALU issue model on a synthetic mix, and the tools that feed it."""
+"""bench.py's host logic on the CPU: the per-rank verification reduce at world 2 and world 8 (one bad rank, or ranks that
+share a device, turn the whole line red), the coefficient-sum invariant's arithmetic, the vector-ALU roofline on the SIMD-32
+peak with a synthetic mix, the bound decision, the extra configurations' generators and checks, and the tools that feed them."""
 import json
 import os
 import sys
@@ -30,7 +31,7 @@ def test_rowsum_mod_p_is_exact_and_is_the_networks_output_zero(oracle):
     assert [int(v) for v in out[:, 0]] == want
 
 
-def _reduce_worker(rank, world, port, q, bad_rank):
+def _reduce_worker(rank, world, rdzv, q, bad_rank, same_device):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -39,10 +40,11 @@ def _reduce_worker(rank, world, port, q, bad_rank):
     import bench
     from conftest import init_gloo_or_report
 
-    if not init_gloo_or_report(rank, world, port, q):
+    if not init_gloo_or_report(rank, world, rdzv, q):
         return
     ok = rank != bad_rank
-    ident = {"rank": rank, "local_device": rank, "pci_bus_id": "0000:%02x:00.0" % (5 + rank), "ms_per_step": 1.5 + rank,
+    bus = 5 if same_device else 5 + rank  # same_device: every rank reports ONE GPU (a mis-bound launch)
+    ident = {"rank": rank, "local_device": rank, "pci_bus_id": "0000:%02x:00.0" % bus, "ms_per_step": 1.5 + rank,
              "round_trip_identical": ok, "coefficient_sum_invariant": True}
     reduced, recs = bench.reduce_verdicts(dist, torch, torch.device("cpu"), world, rank, [ok, True], ident)
     fields, code = bench.verdict_fields(reduced, recs, dist.get_world_size())
@@ -50,21 +52,44 @@ def _reduce_worker(rank, world, port, q, bad_rank):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bad_rank", [-1, 1, 0])
-def test_one_bad_rank_turns_the_line_red(bad_rank):
-    """world-2 gloo: every rank contributes (round trip ok, coefficient sum ok) + its identity; all_reduce(MIN) + all_gather.
-    With every rank good: all_ranks_verified, exit code 0.  With ONE bad rank -- whichever -- every rank learns it, rank 0's
-    line says false and every process exits 1."""
-    res = spawn_world(_reduce_worker, 2, extra_args=(bad_rank,))
+@pytest.mark.parametrize("world,bad_rank", [(2, -1), (2, 1), (2, 0), (8, -1), (8, 5)])
+def test_one_bad_rank_turns_the_line_red(world, bad_rank):
+    """gloo, world 2 and world 8 (the node the driver scales to): every rank contributes (round trip ok, coefficient sum ok) + its
+    identity; all_reduce(MIN) + all_gather_object of `world` identity records.  With every rank good: all_ranks_verified, exit code
+    0.  With ONE bad rank -- whichever, one of eight included -- every rank learns it, rank 0's line says false and every process
+    exits 1."""
+    res = spawn_world(_reduce_worker, world, extra_args=(bad_rank, False))
+    assert len(res) == world
     for rank, code, f in res:
-        assert f["world_size_seen"] == 2 and [r["rank"] for r in f["ranks"]] == [0, 1]  # gathered in rank order
-        assert f["distinct_devices"] == 2 and [r["ms_per_step"] for r in f["ranks"]] == [1.5, 2.5]
+        assert f["world_size_seen"] == world and [r["rank"] for r in f["ranks"]] == list(range(world))  # gathered in rank order
+        assert f["distinct_devices"] == world and [r["ms_per_step"] for r in f["ranks"]] == [1.5 + r for r in range(world)]
+        assert f["verification"]["ranks_on_distinct_devices"] is True
         if bad_rank < 0:
             assert code == 0 and f["all_ranks_verified"] is True
         else:
             assert code == 1 and f["all_ranks_verified"] is False
             assert f["verification"]["round_trip_identical_all"] is False and f["verification"]["coefficient_sum_invariant_all"] is True
-            assert [r["round_trip_identical"] for r in f["ranks"]] == [bad_rank != 0, bad_rank != 1]  # and WHICH rank it was
+            assert [r["round_trip_identical"] for r in f["ranks"]] == [r != bad_rank for r in range(world)]  # and WHICH rank it was
+
+
+def test_ranks_on_one_device_turn_the_line_red():
+    """A world-2 job whose ranks both report the same PCI id (every check passed!) is NOT verified: its aggregate would be one
+    GPU's time-sliced work.  Only the one-device rehearsal switch waives the rule, and the line then says it was waived."""
+    res = spawn_world(_reduce_worker, 2, extra_args=(-1, True))
+    for rank, code, f in res:
+        assert code == 1 and f["all_ranks_verified"] is False and f["distinct_devices"] == 1
+        assert f["verification"]["round_trip_identical_all"] is True and f["verification"]["ranks_on_distinct_devices"] is False
+    import bench
+
+    recs = [{"rank": r, "pci_bus_id": "0000:05:00.0"} for r in range(2)]
+    f, code = bench.verdict_fields([True, True], recs, 2, one_device_ok=True)
+    assert code == 0 and f["all_ranks_verified"] and f["verification"]["distinctness_waived_one_device_rehearsal"] is True
+    # a rank without any identity cannot be shown distinct: red as well
+    f, code = bench.verdict_fields([True, True], [{"rank": 0, "pci_bus_id": "a"}, {"rank": 1, "pci_bus_id": None, "uuid": None}], 2)
+    assert code == 1 and not f["all_ranks_verified"]
+    # fewer records than ranks (a rank that never reported): red
+    f, code = bench.verdict_fields([True, True], [{"rank": 0, "pci_bus_id": "a"}], 2)
+    assert code == 1
 
 
 def test_verdict_fields_single_rank():
@@ -75,41 +100,128 @@ def test_verdict_fields_single_rank():
     assert code == 0 and f["all_ranks_verified"] and f["distinct_devices"] == 1 and f["world_size_seen"] == 1
     f, code = bench.verdict_fields([True, False], [rec], 1)
     assert code == 1 and not f["all_ranks_verified"]
-    f, _ = bench.verdict_fields([True, True], [dict(rec, uuid=None)], 1)
-    assert f["distinct_devices"] is None  # no identity available: said, not guessed
+    f, code = bench.verdict_fields([True, True], [dict(rec, uuid=None)], 1)
+    assert f["distinct_devices"] is None and code == 0  # no identity available: said, not guessed; one rank needs no distinctness
 
 
-def test_weighted_issue_model_arithmetic():
-    """roofline.valu with measured per-class issue costs on a synthetic mix: 22-instruction stream of
-    4 v_mad_u64_u32 at 5 cycles, 16 carry / compare / select forms at 4 and 2 plain moves at 2 = 88 cycles -- the same as a
-    flat 4 -- plus 1.5 overhead instructions at 4: the weighted fraction equals the flat one there, and moves with the costs."""
+def test_valu_roofline_arithmetic_on_a_synthetic_mix():
+    """roofline.valu on the SIMD-32 peak: a wave64 VALU instruction costs 2 cycles of a SIMD's throughput,
+    so 22 instructions per butterfly at 98.2 kernel cycles per wave-butterfly per SIMD is 44 / 98.2 = 0.448 of peak -- not the
+    0.9 a 4-cycle price claimed.  The occupancy-priced second figure (measured issue cost of each instruction class at the
+    kernels' 4 waves per SIMD) is reported under its own name and never as a peak."""
     import bench
 
+    assert bench.VALU_PEAK_CYCLES_PER_WAVE_INSTR == 2.0 and bench.SIMDS == 1024
     mix = {"valu": 22, "salu": 5, "mix": {"mad64": 4, "carry": 14, "cmp64": 1, "cndmask": 1, "plain": 2}}
-    costs = {"mad64": 5.0, "carry": 4.0, "cmp64": 4.0, "cndmask": 4.0, "plain": 2.0, "other": 4.0}
-    assert bench.weighted_issue_cycles(mix, 22.0, costs) == pytest.approx(88.0)
-    assert bench.weighted_issue_cycles(mix, 23.5, costs) == pytest.approx(88.0 + 1.5 * 4.0)
-    assert bench.weighted_issue_cycles(mix, 21.0, costs) == pytest.approx(88.0)  # never negative overhead
-    assert bench.weighted_issue_cycles({"valu": 1, "mix": {"unknown": 1}}, 1.0, costs) == pytest.approx(4.0)  # unpriced class: 4
+    costs = {"mad64": 3.35, "carry": 3.35, "cmp64": 3.35, "cndmask": 3.26, "plain": 1.59, "other": 3.26}
+    stream = 4 * 3.35 + 14 * 3.35 + 3.35 + 3.26 + 2 * 1.59
+    assert bench.weighted_issue_cycles(mix, 22.0, costs, overhead_cycles=3.26) == pytest.approx(stream)
+    assert bench.weighted_issue_cycles(mix, 23.5, costs, overhead_cycles=3.26) == pytest.approx(stream + 1.5 * 3.26)
+    assert bench.weighted_issue_cycles(mix, 21.0, costs) == pytest.approx(stream)  # never negative overhead
+    assert bench.weighted_issue_cycles({"valu": 1, "mix": {"unknown": 1}}, 1.0, costs) == pytest.approx(2.0)  # unpriced class: the peak price
     passes = [("contig", 0, 8), ("col", 8, 8)]
-    bf_waves = 4096 * 32768 * 8 / 64
-    cyc = [1.6e6, 1.5e6]
-    ent = [("k0", {"valu_instr_per_butterfly": 23.5, "held_clock_GHz": 1.93, "kernel_cycles": cyc[0],
-                   "valu_instr_x4cyc_over_kernel_cycles": 23.5 * 4 * bf_waves / (1024 * cyc[0]), "wave_issue_stall_frac": 0.46}),
-           ("k1", {"valu_instr_per_butterfly": 22.0, "held_clock_GHz": 1.96, "kernel_cycles": cyc[1],
-                   "valu_instr_x4cyc_over_kernel_cycles": 22.0 * 4 * bf_waves / (1024 * cyc[1]), "wave_issue_stall_frac": 0.41})]
-    model = {"costs": costs, "streams": [mix, mix], "overhead_cycles": 4.0, "source": "synthetic"}
-    v = bench.valu_roofline(ent, passes, [0.83, 0.80], 4096, 16, issue_model=model)
-    assert v["issue_cycles_per_butterfly_weighted"] == [pytest.approx(94.0), pytest.approx(88.0)]
-    assert v["frac_at_held_clock_weighted"] == pytest.approx(v["frac_at_held_clock"])  # 88 = 22 x 4: same price in total
-    assert v["frac_at_held_clock_weighted_per_pass"][0] == pytest.approx(94.0 * bf_waves / (1024 * cyc[0]))
-    # dearer multiplies: the weighted figure rises, the flat one cannot
-    dear = dict(costs, mad64=6.0)
-    w = bench.valu_roofline(ent, passes, [0.83, 0.80], 4096, 16, issue_model=dict(model, costs=dear))
-    assert w["frac_at_held_clock_weighted"] > v["frac_at_held_clock_weighted"] and w["frac_at_held_clock"] == v["frac_at_held_clock"]
-    assert isinstance(w["saturated"], bool) and ("saturated" in w["verdict"] or "stalls" in w["verdict"])
-    # without a model nothing weighted is claimed
-    assert "frac_at_held_clock_weighted" not in bench.valu_roofline(ent, passes, [0.83, 0.80], 4096, 16)
+    bf_waves = 4096 * 32768 * 8 / 64  # wave-butterflies per launch
+    cyc = [98.2 * bf_waves / 1024, 101.1 * bf_waves / 1024]  # round 4's counters: 98.2 / 101.1 cycles per wave-butterfly per SIMD
+    ent = [("k0", {"valu_instr_per_butterfly": 23.15, "held_clock_GHz": 1.90, "kernel_cycles": cyc[0], "mean_waves_per_simd": 3.7,
+                   "wave_issue_stall_frac": 0.47}),
+           ("k1", {"valu_instr_per_butterfly": 22.20, "held_clock_GHz": 1.95, "kernel_cycles": cyc[1], "mean_waves_per_simd": 3.7,
+                   "wave_issue_stall_frac": 0.41})]
+    v = bench.valu_roofline(ent, passes, [0.83, 0.80], 4096, 16)
+    assert v["peak_cycles_per_wave_instr"] == 2.0
+    assert v["frac_of_peak_at_held_clock_per_pass"] == [pytest.approx(23.15 * 2 / 98.2), pytest.approx(22.20 * 2 / 101.1)]  # 0.47 / 0.44
+    assert v["frac_of_peak_at_held_clock"] == pytest.approx((23.15 + 22.20) * 2 / (98.2 + 101.1))
+    assert v["kernel_cycles_per_wave_butterfly_per_simd"] == [pytest.approx(98.2), pytest.approx(101.1)]
+    assert v["peak_butterflies_per_s"] == pytest.approx(1024 * 2.4e9 / (2 * 22.675) * 64)
+    assert v["saturated"] is False and "NOT saturated" in v["verdict"] and "3.7/3.7 waves" in v["verdict"]
+    assert "issue_cost_at_kernel_occupancy" not in v  # without a model nothing occupancy-priced is claimed
+    for old in ("frac_at_held_clock", "frac_at_held_clock_weighted", "frac_at_2.4GHz"):
+        assert old not in v  # the 4-cycle keys are gone, not aliased
+    model = {"costs": costs, "streams": [mix, mix], "overhead_cycles": 3.26, "waves_per_simd": 4, "source": "synthetic"}
+    w = bench.valu_roofline(ent, passes, [0.83, 0.80], 4096, 16, issue_model=model)
+    ic = w["issue_cost_at_kernel_occupancy"]
+    assert ic["waves_per_simd_priced"] == 4 and ic["cycles_per_butterfly"][0] == pytest.approx(stream + 1.15 * 3.26)
+    assert ic["frac_of_kernel_cycles_per_pass"][0] == pytest.approx((stream + 1.15 * 3.26) / 98.2)
+    assert ic["frac_of_kernel_cycles"] > w["frac_of_peak_at_held_clock"]  # dearer per instruction than the peak price
+    assert w["frac_of_peak_at_held_clock"] == v["frac_of_peak_at_held_clock"]  # ... which it never replaces
+    # a kernel that really sat at the peak would say so
+    fast = [(k, dict(e, kernel_cycles=e["valu_instr_per_butterfly"] * 2 / 0.95 * bf_waves / 1024)) for k, e in ent]
+    assert bench.valu_roofline(fast, passes, [0.4, 0.4], 4096, 16)["saturated"] is True
+
+
+def test_decide_bound_from_the_runs_numbers():
+    """roofline.bound is computed, not asserted: "hbm" / "valu" only at >= 0.9 of that roofline, otherwise what the counters show."""
+    import bench
+
+    assert bench.decide_bound([0.95, 0.93], 0.46)[0] == "hbm"
+    assert bench.decide_bound([0.88, 0.89], 0.93)[0] == "valu"
+    b, why = bench.decide_bound([0.88, 0.89], 0.46, [3.7, 3.7])
+    assert b == "issue-latency" and "0.88" in why and "0.46" in why and "3.7 waves" in why
+    b, why = bench.decide_bound([0.88, 0.89], None)
+    assert b == "issue-latency" and "n/a" in why  # no counters for these sources: neither roofline is claimed
+    assert bench.decide_bound(None, 0.95)[0] == "valu"
+
+
+def test_synthetic_generators_and_config_checks(oracle):
+    """The extra configurations' host logic: the 32-bit generator equals splitmix64 mod p on Python integers; the coefficient-sum
+    invariant for 4-byte words; evaluation at a root of x^N + 1 accepts the oracle's negacyclic product and rejects a wrong word."""
+    import torch
+
+    import bench
+
+    p, n = 3221225473, 64
+    got = bench.synth_u32(torch, 3, n, p, torch.device("cpu"), first_row=7).numpy().view(np.uint32)
+
+    def sm(i):
+        z = (i + 0x9E3779B97F4A7C15) & (2**64 - 1)
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        return z ^ (z >> 31)
+
+    want = [[sm(bench.SEED + (7 + b) * n + i) % p for i in range(n)] for b in range(3)]
+    assert got.tolist() == want
+    assert bench.rowsum_mod_p_u32(got, p) == [sum(r) % p for r in want]
+    T = oracle.make_roots(n, p, 5, 4)
+    assert [int(v) for v in oracle.ntt(got, T, p)[:, 0]] == [sum(r) % p for r in want]
+    # negacyclic product by schoolbook, checked by evaluation at r = g^((p-1)/2N), r^N = -1
+    P, N = GOLD, 32
+    rng = np.random.default_rng(9)
+    a = (rng.integers(0, 2**63, size=N, dtype=np.uint64) % np.uint64(P))
+    b = (rng.integers(0, 2**63, size=N, dtype=np.uint64) % np.uint64(P))
+    c = [0] * N
+    for i in range(N):
+        for j in range(N):
+            t = int(a[i]) * int(b[j])
+            if i + j < N:
+                c[i + j] = (c[i + j] + t) % P
+            else:
+                c[i + j - N] = (c[i + j - N] - t) % P
+    r = pow(7, (P - 1) // (2 * N), P)
+    assert pow(r, N, P) == P - 1
+    cv = np.array(c, dtype=np.uint64)
+    assert bench.poly_eval_mod(cv, r, P) == bench.poly_eval_mod(a, r, P) * bench.poly_eval_mod(b, r, P) % P
+    cv[5] ^= np.uint64(1)
+    assert bench.poly_eval_mod(cv, r, P) != bench.poly_eval_mod(a, r, P) * bench.poly_eval_mod(b, r, P) % P
+
+
+def test_tagged_profile_picks_the_newest_collection_on_these_sources(tmp_path, monkeypatch):
+    """Counters are quoted from the newest profiles/rNN_<name>.json whose stamped kernel-source hash equals the tree's -- an older
+    round's file when this round did not touch the kernels, nothing at all when no file matches."""
+    import bench
+
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    for rnd, h in (("r03", "aaa"), ("r04", "bbb"), ("r05", "ccc")):
+        (prof / ("%s_pmc_traffic.json" % rnd)).write_text(json.dumps({"src_hash": h, "round": rnd}))
+    (prof / "r04_cfg2_pmc_traffic.json").write_text(json.dumps({"src_hash": "bbb", "round": "cfg2"}))  # another name: never confused
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    d, why = bench.tagged_profile("pmc_traffic", "bbb")
+    assert d["round"] == "r04" and "r04_pmc_traffic.json" in why
+    d, why = bench.tagged_profile("pmc_traffic", "ccc")
+    assert d["round"] == "r05"
+    d, why = bench.tagged_profile("pmc_traffic", "zzz")
+    assert d is None and "not quoted" in why and "r05_pmc_traffic.json: ccc" in why
+    d, why = bench.tagged_profile("sq_counters", "bbb")
+    assert d is None and "absent" in why
 
 
 def test_stream_mix_comes_from_the_generator():

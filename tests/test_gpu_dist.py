@@ -5,33 +5,29 @@ ranks only the number of receivers changes.  Reference analogue: the on-chip bro
 every tile, src/aie2.py:96-104."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
 import pytest
 
-from conftest import ROOT, run_with_fresh_port
+from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
 
 
-def _free_port() -> int:
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
+def _env() -> dict:
+    """One rank, no MASTER_ADDR / MASTER_PORT: the process groups below rendezvous through a file (no TCP port to collide on;
+    round 4's EADDRINUSE came from probing a port, releasing it and handing the number over)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_ADDR", "MASTER_PORT")}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
 
 
-def _env(port: int) -> dict:
-    return dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0",
-                WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-
-
-def test_bench_force_dist_nccl_world1():
-    """bench.py with --force-dist: the nccl branch of bench.py and of dist.broadcast_table run end to end."""
-    out = run_with_fresh_port(lambda port: subprocess.run(
+def test_bench_force_dist_nccl_world1(tmp_path):
+    """bench.py with --force-dist: the nccl branch of bench.py and of dist.broadcast_table run end to end (file rendezvous)."""
+    out = subprocess.run(
         [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "2", "--warmup", "1", "--batch", "64",
-         "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=_env(port)))
+         "--no-cpu-baseline", "--rdzv-file", str(tmp_path / "store")], capture_output=True, text=True, timeout=900, env=_env())
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["steps"] == 2
@@ -47,7 +43,7 @@ def test_broadcast_table_under_nccl_group(tmp_path):
         "sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, 'oracle'))\n"
         "import numpy as np, torch, torch.distributed as dist\n"
         "torch.cuda.set_device(0)\n"
-        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "dist.init_process_group('nccl', init_method='file://' + sys.argv[1], rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
         "assert dist.get_backend() == 'nccl'\n"
         "from ntt_aie_amd.dist import ShardedNTT, broadcast_table, shard_rows\n"
         "from ntt_aie_amd import NTTPlan, to_device, to_host\n"
@@ -66,6 +62,5 @@ def test_broadcast_table_under_nccl_group(tmp_path):
         "assert np.array_equal(to_host(eng.inverse_local(f)), a)\n"
         "dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()\n"
         "print('NCCL_BCAST_OK')\n" % (ROOT, ROOT))
-    out = run_with_fresh_port(lambda port: subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900,
-                                                          env=_env(port)))
+    out = subprocess.run([sys.executable, str(script), str(tmp_path / "store")], capture_output=True, text=True, timeout=900, env=_env())
     assert out.returncode == 0 and "NCCL_BCAST_OK" in out.stdout, (out.stdout + out.stderr)[-3000:]

@@ -418,13 +418,16 @@ def test_bench_two_ranks_rehearsal():
     import subprocess
     import sys
 
-    from conftest import ROOT, run_with_fresh_port
+    from conftest import ROOT
 
-    env = dict(os.environ, NTT_BENCH_ONE_DEVICE="1", NTT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = run_with_fresh_port(lambda port: subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256"],
-        capture_output=True, text=True, timeout=900, env=env))
+    # the launcher owns its rendezvous (--standalone: the agent binds port 0 itself and the ranks reuse its store): no port is
+    # probed and handed over, a failed launch fails the test
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_ADDR", "MASTER_PORT", "RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(NTT_BENCH_ONE_DEVICE="1", NTT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", "2",
+         os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "256"],
+        capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # rank 0 only

@@ -385,15 +385,15 @@ def test_bench_quotes_only_matching_forward_counters():
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     r = d["roofline"]
     assert d["config"]["baseline_config"] == 3 and "inverse" not in d
-    path = os.path.join(ROOT, "profiles", "%s_pmc_traffic.json" % bench.PROFILE_ROUND)
-    stamped = json.load(open(path))["src_hash"] if os.path.exists(path) else None
-    if stamped == _lib.kernel_source_hash():
+    have, _ = bench.tagged_profile("pmc_traffic", _lib.kernel_source_hash())  # the newest committed collection on exactly these sources
+    if have is not None:
         assert r["traffic"] is not None and 1.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 2.1  # two trips, no over-fetch
         assert "forward kernels" in r["traffic_source"] and ", true," not in r["traffic_source"].split("forward kernels:")[1].replace("true, false", "")
         v = r["valu"]
-        assert v is not None and all(20 < x < 26 for x in v["instr_per_butterfly"]) and 0 < v["frac_at_held_clock"] <= 1
+        assert v is not None and all(20 < x < 26 for x in v["instr_per_butterfly"]) and 0 < v["frac_of_peak_at_held_clock"] < 1
         assert all("false" in k.split(",")[4] for k in v["kernels"])  # PassCfg<F, LOG_M, LOG_C, CONTIG, INV, ...>: INV == false
-        if v.get("issue_model"):  # the weighted figure rides on the same counters
-            assert 0 < v["frac_at_held_clock_weighted"] < 1.2 and len(v["issue_cycles_per_butterfly_weighted"]) == 2
+        ic = v.get("issue_cost_at_kernel_occupancy")
+        if ic:  # the occupancy-priced figure rides on the same counters
+            assert 0 < ic["frac_of_kernel_cycles"] < 1.2 and len(ic["cycles_per_butterfly"]) == 2
     else:
         assert r["traffic"] is None and r["valu"] is None and ("not quoted" in r["traffic_source"] or "absent" in r["traffic_source"])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of every BASELINE.json configuration that fits one GPU (not the driver's bench.py: that one reports the
 headline config only), one JSON object per line, each with a `roofline` object carrying the same keys as bench.py's
-(`bound`, `achieved`, `peak`, `unit`, `frac`, `frac_ceiling`, `traffic`, `valu`).
+(`bound`, `achieved`, `peak`, `unit`, `frac`, `frac_ceiling`, `traffic`, `valu`) -- made by the same function, bench.config_roofline.
 
 Timing is live (hipEvents on the launch stream around a loop of operations, and ntt_forward_profile per pass).  Counter
 figures (`traffic`, `valu`) are quoted from profiles/<round>_<cfg>_pmc_traffic.json / _sq_counters.json -- written by
@@ -22,7 +22,6 @@ import bench
 from configs import CONFIGS, GOLD, algorithmic_bytes, butterflies
 from ntt_aie_amd import NTTPlan, _lib
 
-HBM_PEAK_GBS = bench.HBM_PEAK_GBS
 
 
 def rand(batch, n, wb, p, seed):
@@ -48,54 +47,11 @@ def timeit(fn, steps=20, warmup=8):
     return e0.elapsed_time(e1) / steps
 
 
-def quoted(cfg_key, name, src_hash):
-    d, why = bench.tagged_profile("%s_%s" % (cfg_key, name), src_hash)
-    return d, why
-
-
 def roofline(cfg_key, c, op_ms, pass_ms, copy_ms, passes):
-    """bench.py's roofline keys for one configuration.  achieved = algorithmic bytes per operation / time per operation
-    (a transform: the summed hipEvent durations of its pass kernels when ntt_forward_profile gave them)."""
-    src_hash = _lib.kernel_source_hash()
-    alg = float(algorithmic_bytes(c))
-    t = (sum(pass_ms) if pass_ms else op_ms) * 1e-3
-    achieved = alg / t / 1e9
-    pmc, pmc_src = quoted(cfg_key, "pmc_traffic", src_hash)
-    sq, sq_src = quoted(cfg_key, "sq_counters", src_hash)
-    traffic = pmc["per_op"]["hbm_bytes"] if pmc else None
-    valu = None
-    if sq:
-        valu = {"instr_per_butterfly": sq["per_op"]["valu_instr_per_butterfly"],
-                "frac_at_held_clock": sq["per_op"]["valu_instr_x4cyc_over_kernel_cycles"],
-                "kernels": {k: {"short": v["short"], "valu_instr_per_butterfly": v["valu_instr_per_butterfly"],
-                                "valu_instr_x4cyc_over_kernel_cycles": v.get("valu_instr_x4cyc_over_kernel_cycles"),
-                                "mean_waves_per_simd": v.get("mean_waves_per_simd"), "held_clock_GHz": v.get("held_clock_GHz"),
-                                "duration_us": v.get("duration_us"), "launches_per_op": v["launches_per_op"],
-                                "wave_issue_stall_frac": v.get("wave_issue_stall_frac")} for k, v in sq["kernels"].items()},
-                "what": "SQ_INSTS_VALU per operation / (butterflies per operation / 64); frac_at_held_clock = instructions x 4 cycles / "
-                        "(1024 SIMDs x GRBM_GUI_ACTIVE / 8), clock-free"}
-    # physical trips through HBM on the convention the algorithmic bytes use: a transform moves 2N words per pass; the product's
-    # fused schedule (inverse column passes of a and b 4N, fused middle 3N, forward column pass 2N) moves exactly the 9N it is priced on
-    ceiling = 1.0 if c["op"] == "polymul" else 1.0 / max(1, passes)
-    copy_gbs = alg / (copy_ms * 1e-3) / 1e9 if copy_ms else None
-    # which unit binds, by what the numbers of THIS run and the quoted counters say
-    if valu and valu["frac_at_held_clock"] is not None and valu["frac_at_held_clock"] >= 0.75:
-        bound, why = "valu", "VALU instruction count x 4 cycles fills %.0f %% of the kernels' cycles" % (100 * valu["frac_at_held_clock"])
-    elif copy_gbs and achieved / ceiling >= 0.8 * copy_gbs:
-        bound, why = "hbm", "each trip streams at %.0f %% of a device copy of the same bytes" % (100 * achieved / ceiling / copy_gbs)
-    elif op_ms < 0.05:
-        bound, why = "latency", ("one generation of workgroups: a %.1f us launch is a workgroup's own load -> butterflies -> store chain, "
-                                 "not a throughput limit" % (op_ms * 1e3))
-    else:
-        bound, why = "valu+hbm", "neither unit alone is saturated (power-capped mix, DESIGN.md section 4)"
-    return {"bound": bound, "bound_evidence": why, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "frac_ceiling": ceiling,
-            "traffic": traffic, "traffic_ratio_to_algorithmic": (traffic / alg if traffic else None), "traffic_source": pmc_src,
-            "valu": valu, "valu_source": sq_src,
-            "algorithmic_bytes_per_op": alg, "device_copy_same_bytes_GBs": copy_gbs,
-            "frac_of_device_copy": (achieved / copy_gbs if copy_gbs else None),
-            "definition": "algorithmic bytes of one operation (SURVEY 8d: 2N words per transform, 9N per product) / %s"
-                          % ("summed hipEvent durations of its pass kernels" if pass_ms else "hipEvent time per operation")}
+    """bench.py's roofline object for one configuration (bench.config_roofline: the same function the driver-run line uses).
+    A transform is priced on the summed hipEvent durations of its pass kernels when ntt_forward_profile gave them."""
+    t = sum(pass_ms) if pass_ms else op_ms
+    return bench.config_roofline(cfg_key, c, t, copy_ms, passes, _lib.kernel_source_hash())
 
 
 def run(name, logn, p, g, wb, batch, kind=0, polymul=False, cfg_key=None):

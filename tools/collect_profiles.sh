@@ -14,8 +14,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-valu-floor"
-BENCH5="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-valu-floor"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-valu-floor --no-configs"
+BENCH5="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-valu-floor --no-configs"
 SQCNT="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE"
 # the weighted VALU model's inputs first: measured issue cost per instruction class, exact stream mix (stamped with the source hash)
 if [ -x "$ROOT/tools/valu_issue_cost" ]; then

@@ -21,9 +21,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from configs import CONFIGS, algorithmic_bytes, butterflies
+from hw import SIMDS, valu_frac_of_peak
 from kernel_key import parse_kernel
-
-SIMDS = 1024
 
 
 def transforms_per_op(cfg: dict, pk: dict) -> int:
@@ -101,8 +100,8 @@ def summarize_sq(cfg_key, ops, sq_csv, src_hash=None):
                    "SQ_INSTS_SALU GRBM_GUI_ACTIVE of tools/config_profile.py; per kernel, means per launch; valu_instr_per_butterfly = "
                    "SQ_INSTS_VALU per operation / (butterflies this kernel runs per operation / 64): the product kernel runs three "
                    "LOG_M-stage networks per polynomial and its two word-by-word products count as overhead on those; SQ_* cycle "
-                   "counters are quad-cycles summed over waves; kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs; valu_instr_x4cyc_over_"
-                   "kernel_cycles prices every VALU instruction at 4 cycles (an instruction-count estimate)")
+                   "counters are quad-cycles summed over waves; kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs; valu_frac_of_peak prices every VALU "
+                   "instruction at the 2 cycles a wave64 instruction takes on a SIMD-32 (tools/hw.py): the vector ALU's share of its peak")
     out["kernels"] = {}
     tot_valu = tot_cyc = tot_bf = 0.0
     for key, d in sq.items():
@@ -130,7 +129,7 @@ def summarize_sq(cfg_key, ops, sq_csv, src_hash=None):
                     e["wave_issue_stall_frac"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
                 if "SQ_WAIT_ANY" in m:
                     e["wave_parked_frac"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
-            e["valu_instr_x4cyc_over_kernel_cycles"] = m["SQ_INSTS_VALU"] * 4 / cyc / SIMDS
+            e["valu_frac_of_peak"] = valu_frac_of_peak(m["SQ_INSTS_VALU"], cyc)
             tot_cyc += cyc * per_op
         tot_valu += m["SQ_INSTS_VALU"] * per_op
         tot_bf += bf_op
@@ -138,7 +137,7 @@ def summarize_sq(cfg_key, ops, sq_csv, src_hash=None):
     out["per_op"] = {"valu_instr": tot_valu, "butterflies_in_profiled_kernels": tot_bf,
                      "valu_instr_per_butterfly": tot_valu / (tot_bf / 64.0) if tot_bf else None,
                      "kernel_cycles": tot_cyc,
-                     "valu_instr_x4cyc_over_kernel_cycles": tot_valu * 4 / (tot_cyc * SIMDS) if tot_cyc else None}
+                     "valu_frac_of_peak": valu_frac_of_peak(tot_valu, tot_cyc) if tot_cyc else None}
     return out
 
 

@@ -10,7 +10,7 @@ mkdir -p $OUT
 : > $OUT/mi355x_rocprof.csv
 for L in 8 9 10 11 12 13 14 15 16 17; do
   D=$GRAFT_REPO_ROOT/gpurun_out/kt_$L
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $D -o run -- python3 $GRAFT_REPO_ROOT/tools/archive/one_size.py $L > /dev/null 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $D -o run -- python3 $GRAFT_REPO_ROOT/tools/one_size.py $L > /dev/null 2>&1)
   python3 - "$D" $L >> $OUT/mi355x_rocprof.csv <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]

@@ -2,7 +2,7 @@
 """30 forward launches of one size at batch 1 (p = 3329, the reference's parameter set) -- the program rocprofv3 wraps
 in tools/kerneltime_rocprof.sh to read true kernel durations.  usage: one_size.py LOGN"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 from ntt_aie_amd import NTTPlan, to_device

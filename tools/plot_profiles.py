@@ -10,6 +10,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from hw import PEAK_GOPS_INT32  # noqa: E402
 
 # the reference's recorded series (profile/kerneltime/aie.csv, gpu.csv): N, kernel microseconds
 AIE_KERNEL_US = {512: 8.86256, 1024: 10.67568, 2048: 14.3748, 4096: 22.06464}
@@ -17,9 +19,10 @@ A100_KERNEL_US = {256: 12.004, 512: 13.497, 1024: 16.365, 2048: 21.510, 4096: 19
                   32768: 31.337, 65536: 45.942, 131072: 81.350}
 # peaks the reference divides by (profile/plot_efficiency.py:27, 46): A100 4280 GOPS, AIE 88 GOPS
 PEAK_GOPS = {"aie": 88.0, "a100": 4280.0,
-             # MI355X: 32-bit integer vector rate, 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz (one op per lane-clock;
-             # wave64 integer instructions issue over 4 cycles on gfx950: profiles/r01_microbench2_valu_forms.txt)
-             "mi355x": 256 * 4 * 16 * 2.4}
+             # MI355X: 32-bit integer vector rate, 256 CUs x 4 SIMD-32 x 32 lanes per clock x 2.4 GHz = 78.6 TOPS (tools/hw.py;
+             # MI355X_MICROARCH.md: a wave64 instruction takes 2 cycles of a SIMD's throughput).  Rounds 1-4 divided by a 16-lane
+             # figure -- what ONE wave alone sustains -- and published efficiencies above 1; a stated peak must not be exceeded.
+             "mi355x": PEAK_GOPS_INT32}
 # the reference's 16-tile launch-to-completion series, trimmed means of profile/exectime/ntt_16core_logn*.csv (plot_exectime.py rule)
 AIE16_EXEC_US = {256: 288.4, 512: 261.8, 1024: 274.8, 2048: 279.4, 4096: 288.0, 8192: 319.4}
 
