@@ -28,6 +28,10 @@ struct ErasedArgs {
     const void *skip_if;  // experiment build only: device word, non-zero = the launch is a no-op (fallback behind the fused kernel)
     int variant;          // PassDesc::variant (plan.h): 0 = the default kernel of this (contig, log_m); 1 = single-pass CONTIG unit of 10..12
                           // stages as radix-8 rounds in 512 threads (twice the waves per unit: small batches, one generation of workgroups)
+#if defined(NTT_PHASE_STAMPS)
+    void *stamps;            // diagnostic build: PassArgs::stamps / stamp_records (ntt_stamps_set)
+    uint32_t stamp_records;
+#endif
 };
 
 // Each returns hipSuccess / a hipError_t; hipErrorInvalidValue for an

@@ -156,6 +156,11 @@ const std::vector<PassDesc> &passes_for(const ntt_plan *pl, size_t batch) {
     return pl->alts[(size_t) k].passes;
 }
 
+#if defined(NTT_PHASE_STAMPS)
+void *g_stamp_buf = nullptr;  // diagnostic build: ntt_stamps_set()
+uint32_t g_stamp_records = 0;
+#endif
+
 ntt::ErasedArgs base_args(const ntt_plan *pl, const PassDesc &pd, const void *in, void *out, size_t batch) {
     ntt::ErasedArgs a;
     memset(&a, 0, sizeof(a));
@@ -175,6 +180,12 @@ ntt::ErasedArgs base_args(const ntt_plan *pl, const PassDesc &pd, const void *in
     a.variant = pd.variant;
 #if defined(NTT_EXPERIMENT)
     if (pl->force_variant >= 0 && pd.contig) a.variant = pl->force_variant;  // NTT_PASS_VARIANT=k: A/B of a kernel variant
+#endif
+#if defined(NTT_PHASE_STAMPS)
+    // one region per pass kind, so that the passes of one transform do not overwrite each other's records: the CONTIG pass
+    // takes the first half of the buffer, a column pass the second (tools/phase_stamps.py stamps two-pass transforms)
+    a.stamp_records = g_stamp_records / 2;
+    a.stamps = g_stamp_buf ? (char *) g_stamp_buf + (pd.contig ? 0 : (size_t) a.stamp_records * ntt::STAMP_RECORD * 8) : nullptr;
 #endif
     return a;
 }
@@ -256,6 +267,17 @@ int run_inverse(ntt_plan *pl, const void *d_in, void *d_out, size_t batch, int l
 extern "C" {
 
 int ntt_version(void) { return 400; /* 0.4.0 */ }
+
+#if defined(NTT_PHASE_STAMPS)
+// Diagnostic side build only (tools/ab_build.sh stamps -DNTT_PHASE_STAMPS -> ab/libntt_stamps.so; tools/phase_stamps.py): where
+// the pass kernels of this process write their phase stamps (pass.h: stamp()).  [records][ntt::STAMP_RECORD] 64-bit slots, one
+// record per wave of a launch; null = stamps go to a dummy record.  Never declared in include/ntt_hip.h.
+int ntt_stamps_set(void *d_buf, size_t records) NTT_GUARD {
+    g_stamp_buf = d_buf;
+    g_stamp_records = (uint32_t) (records > 0xFFFFFFFFull ? 0xFFFFFFFFull : records);
+    return NTT_OK;
+} NTT_GUARD_END
+#endif
 
 #if defined(NTT_EXPERIMENT)
 // libntt_hip_exp.so only (never declared in include/ntt_hip.h, never exported by the product): the timing switches of

@@ -71,6 +71,35 @@ enum { LAYOUT_NATURAL = 0, LAYOUT_AIE_BLOCK16 = 1 };
 // half of the 4-bit block index (1<->2, 4<->8, 5<->10, 6<->9, 7<->11, 13<->14).
 NTT_HD constexpr uint32_t aie_block16(uint32_t b) { return ((b & 5u) << 1) | ((b >> 1) & 5u); }
 
+// ---- phase stamps: a DIAGNOSTIC build only (-DNTT_PHASE_STAMPS, ab/libntt_stamps.so, tools/phase_stamps.py) -----------------
+// The reference records a per-event trace of one tile (src/aie_core.cc:129-131 event0()/event1(), profile/trace/*.json); the
+// analogue here is an s_memtime stamp at every phase boundary of run_pass(), written by lane 0 of every wave to a record of
+// its own.  stamp(ex, k) calls ex.stamp(k) when the executor has one and is nothing otherwise: the product and experiment
+// builds, the fused tools-side schedule and the host index model carry no trace of it.
+// Stamp k of iteration `it` (R = register rounds):  0 iteration begins | 1 tile landed (LDS-DMA kernels; otherwise = 0) |
+// 2 first round's words in registers (next tile's prefetch issued) | 3 + 2r round r computed | 4 + 2r exchange after round r
+// done | 2R + 2 stores issued | 2R + 3 end-of-iteration sync passed.
+template <class E>
+NTT_HD auto stamp_impl(E &ex, int k, int) -> decltype(ex.stamp(k), void()) {
+    ex.stamp(k);
+}
+template <class E>
+NTT_HD void stamp_impl(E &, int, long) {}
+template <class E>
+NTT_HD void stamp(E &ex, int k) {
+    stamp_impl(ex, k, 0);
+}
+constexpr int STAMPS_PER_ITER = 12;    // 2R + 4 <= 12 for R <= 4
+constexpr int STAMP_HEADER = 4;        // 0 s_memrealtime at start, 1 s_memtime at start, 2 HW_ID | XCC_ID << 32, 3 iterations completed
+constexpr int STAMP_RECORD = 128;      // 64-bit slots per wave: header + 8 iterations x 12 stamps, [126] s_memtime / [127] s_memrealtime at the end
+#if defined(NTT_PHASE_STAMPS)
+// every stamp is one more VMEM store of the wave: the LDS-DMA kernels' counted wait (phase_dma_wait) has to know how many of
+// them are younger than the prefetch -- stamps 2 .. 2R+3 of the iteration that issued it and stamp 0 of the next one
+#define NTT_STAMP_EXTRA_VM(R) (2 * (R) + 3)
+#else
+#define NTT_STAMP_EXTRA_VM(R) 0
+#endif
+
 template <int I, int N, class Fn>
 NTT_HD void static_for(Fn &&f) {
     if constexpr (I < N) {
@@ -240,6 +269,10 @@ struct PassArgs {
                    // timing experiments: 1 = every iteration re-reads polynomial group 0,
                    // 2 = skip the direct stores, 4 = every iteration stores to polynomial group 0
     W scale;
+#if defined(NTT_PHASE_STAMPS)
+    unsigned long long *stamps;  // [stamp_records][STAMP_RECORD] 64-bit slots, one record per wave of the launch (null: stamps go to a dummy record)
+    uint32_t stamp_records;
+#endif
 };
 
 template <class Cfg>
@@ -806,7 +839,7 @@ template <class Cfg, bool FIRST_ITER>
 NTT_HD void phase_dma_wait() {
 #if defined(__HIP_DEVICE_COMPILE__)
     if constexpr (FIRST_ITER) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::E) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::E + NTT_STAMP_EXTRA_VM(Cfg::R)) : "memory");
 #endif
 }
 
@@ -1095,9 +1128,12 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         if (!ex.iter_begin(it)) break;  // fused schedule: wait for the producer of this polynomial (uniform)
         ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, it); });
         typename Cfg::W *const tile = Cfg::DMA ? ex.lds() + (it & 1) * Cfg::TILE_WORDS : ex.lds();
+        const int sb = it * STAMPS_PER_ITER;  // (diagnostic build only: stamp() is nothing elsewhere)
+        stamp(ex, sb + 0);
         if constexpr (Cfg::DMA) {
             if (it == 0) ex.each([&](C &) { phase_dma_wait<Cfg, true>(); });
             else ex.each([&](C &) { phase_dma_wait<Cfg, false>(); });
+            stamp(ex, sb + 1);
             prio_up();
             if (group_valid(it + 1)) ex.each([&](C &c) { phase_dma_issue<Cfg>(c, a, ex.lds(), it + 1); });
             prio_down();
@@ -1114,15 +1150,18 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.sync(std::integral_constant<bool, FIRST == 0 || Cfg::WAVE_LOCAL>{});  // (an inverse pass staged this way is a small, wave-local unit)
             ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, tile, Cfg::INV && block16_here<Cfg>(a)); });
         }
+        stamp(ex, sb + 2);  // (the diagnostic build's stamp waits for the words: s_waitcnt vmcnt / lgkmcnt, see GpuExec::stamp)
         static_for<0, R>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
             constexpr int r = Cfg::INV ? R - 1 - k : k;
             ex.each([&](C &c) { phase_compute<Cfg, r, M32_MODE, false, SC>(c, a); });
+            stamp(ex, sb + 3 + 2 * k);
             if constexpr (k < R - 1) {
                 constexpr int rn = Cfg::INV ? r - 1 : r + 1;
                 ex.each([&](C &c) { phase_lds_write<Cfg, r>(c, tile); });
                 ex.sync(std::integral_constant<bool, Cfg::exchange_wave_local(r, rn)>{});
                 ex.each([&](C &c) { phase_lds_read<Cfg, rn>(c, tile); });
+                stamp(ex, sb + 4 + 2 * k);
             }
         });
         // (a configuration that CAN fold the scaling never runs the sweep: its launcher picks SC whenever do_scale is set, so
@@ -1136,11 +1175,13 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.sync(std::integral_constant<bool, LAST == 0 || Cfg::WAVE_LOCAL>{});  // round 0's words of a wave's threads are that wave's segment of the linear copy
             ex.each([&](C &c) { phase_linear_store<Cfg>(c, a, tile, it); });
         }
+        stamp(ex, sb + 2 * R + 2);
         ex.iter_done(it);  // fused schedule: publish the previous polynomial's tile
         ++completed;
         if constexpr (ANY_LDS) {
             ex.sync(std::integral_constant<bool, Cfg::WAVE_LOCAL>{});  // next iteration rewrites the tile
         }
+        stamp(ex, sb + 2 * R + 3);
     }
     ex.pass_done(completed);
 }

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Where the cycles of the two headline pass kernels go: s_memtime stamps at every phase boundary of run_pass() (pass.h:
+stamp()), written by lane 0 of EVERY wave of a launch of the diagnostic build ab/libntt_stamps.so
+(`tools/ab_build.sh stamps -DNTT_PHASE_STAMPS`; the product and experiment libraries contain no stamp), reduced to a per-phase
+cycle table.  The reference's analogue: the per-event hardware trace of one tile bracketed by event0()/event1()
+(src/aie_core.cc:129-131, profile/trace/trace_16core_n11.json -- 63 % LockStall).
+
+usage (GPU box): python3 tools/phase_stamps.py [--logn 16] [--batch 4096] [--reps 10] > profiles/rNN_phase_stamps.json
+
+What is measured: the forward transform at the headline shape, `reps` back-to-back launches with stamps on (the last launch's
+records are read).  A stamp waits for the wave's outstanding LDS traffic (and, in kernels that load straight into registers,
+its global loads) before it reads the clock, so a phase ends when its data has arrived; stamping itself costs cycles -- the
+`overhead` entry compares the stamped launch's duration with the product library's in the same process.  Outputs of the stamped
+launch are compared word for word with the product library's."""
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np  # noqa: E402
+
+REC, HDR, PER_IT = 128, 4, 12  # pass.h: STAMP_RECORD, STAMP_HEADER, STAMPS_PER_ITER
+
+
+def phase_names(R, dma):
+    """name of the interval that ENDS at stamp k (k = 1 .. 2R+3)"""
+    names = {1: "wait: tile landed in LDS (LDS-DMA prefetch issued one iteration earlier)" if dma else "(no separate tile stamp)",
+             2: ("issue the next tile's LDS-DMA prefetch + read round 0's words from LDS" if dma else
+                 "global loads straight into the round registers, issued and waited for")}
+    for r in range(R):
+        names[3 + 2 * r] = "round %d butterflies (register stages)" % r
+        if r < R - 1:
+            names[4 + 2 * r] = "exchange %d -> %d through LDS (write, sync, read)" % (r, r + 1)
+    names[2 * R + 2] = "canonicalise + issue the stores"
+    names[2 * R + 3] = "end-of-iteration sync"
+    return names
+
+
+def group_of(name):
+    if name.startswith("round"):
+        return "compute (register rounds)"
+    if name.startswith("exchange"):
+        return "exchange (LDS)"
+    if "sync" in name or "loop" in name:
+        return "sync + loop"
+    return "memory (tile wait / loads / stores)"
+
+
+def reduce_region(recs, R, dma, log_m, e_words, nt):
+    """recs: [records][128] uint64 of one pass kind -> the per-phase table: steady-state iterations (it >= 1), iteration 0 apart.
+    Pure numpy (CPU unit test: tests/test_profile_tools.py)."""
+    recs = np.asarray(recs, dtype=np.uint64)
+    live = recs[recs[:, 1] != 0]
+    out = {"waves_sampled": int(len(live)), "rounds": R, "stages": log_m, "threads_per_workgroup": nt, "words_per_thread": e_words}
+    if not len(live):
+        return out
+    iters = live[:, 3].astype(np.int64)
+    life = (live[:, REC - 2] - live[:, 1]).astype(np.float64)
+    real = (live[:, REC - 1] - live[:, 0]).astype(np.float64)  # s_memrealtime: 100 MHz
+    out["clock_GHz_median"] = float(np.median(life / np.maximum(1.0, real) * 0.1))
+    out["iterations_per_wave"] = {"min": int(iters.min()), "median": float(np.median(iters)), "max": int(iters.max())}
+    out["wave_lifetime_cycles_median"] = float(np.median(life))
+    # kernel entry -> the first iteration's first stamp: index set-up + the resident twiddle loads
+    out["init_cycles_median"] = float(np.median(live[:, HDR].astype(np.float64) - live[:, 1].astype(np.float64)))
+    nst = 2 * R + 4
+    names = phase_names(R, dma)
+    steady = {k: [] for k in range(1, nst)}
+    cold = {k: [] for k in range(1, nst)}
+    gaps, it_total, it0_total = [], [], []
+    for row, n_it in zip(live, iters):
+        t = row[HDR:HDR + 8 * PER_IT].astype(np.float64).reshape(8, PER_IT)
+        if not dma:
+            t[:, 1] = t[:, 0]  # kernels without an LDS-DMA tile write no stamp 1: the load phase runs from stamp 0 to stamp 2
+        for it in range(min(int(n_it), 8)):
+            d = np.diff(t[it, :nst])
+            tgt = cold if it == 0 else steady
+            for k in range(1, nst):
+                tgt[k].append(d[k - 1])
+            (it0_total if it == 0 else it_total).append(t[it, nst - 1] - t[it, 0])
+            if it + 1 < n_it and it + 1 < 8:
+                gaps.append(t[it + 1, 0] - t[it, nst - 1])
+    if not it_total:  # one iteration per wave: report that one
+        steady, it_total = cold, it0_total
+        out["note"] = "every wave ran ONE iteration: the table is iteration 0"
+    bf_per_thread = (e_words // 2) * log_m  # butterflies per thread per iteration = wave-butterflies per wave-iteration
+    gap = float(np.mean(gaps)) if gaps else 0.0
+    tot = float(np.mean(it_total)) + gap
+    phases = []
+    for k in range(1, nst):
+        if not dma and k == 1:
+            continue
+        m = float(np.mean(steady[k]))
+        phases.append({"ends_at_stamp": k, "phase": names[k], "cycles_mean": m, "cycles_median": float(np.median(steady[k])),
+                       "share_of_iteration": m / tot, "cycles_mean_iteration0": float(np.mean(cold[k])) if cold[k] else None})
+    if gaps:
+        phases.append({"ends_at_stamp": 0, "phase": "loop back to the next iteration's first stamp", "cycles_mean": gap,
+                       "cycles_median": float(np.median(gaps)), "share_of_iteration": gap / tot, "cycles_mean_iteration0": None})
+    out["iteration_cycles_mean_steady"] = tot
+    out["iteration_cycles_mean_first"] = float(np.mean(it0_total)) if it0_total else None
+    out["wave_butterflies_per_iteration"] = bf_per_thread
+    out["wave_elapsed_cycles_per_wave_butterfly"] = tot / bf_per_thread
+    grp = {}
+    for ph in phases:
+        grp[group_of(ph["phase"])] = grp.get(group_of(ph["phase"]), 0.0) + ph["cycles_mean"]
+    out["split"] = {k: {"cycles": v, "share": v / tot} for k, v in grp.items()}
+    out["phases"] = phases
+    return out
+
+
+def main():
+    import torch
+
+    from bench import GOLDILOCKS, synth_batch
+    from ntt_aie_amd import _lib
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--logn", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--lib", default=os.path.join(ROOT, "ab", "libntt_stamps.so"))
+    args = ap.parse_args()
+    torch.cuda.set_device(0)
+    n = 1 << args.logn
+    x = synth_batch(torch, args.batch, n, torch.device("cuda", 0))
+    y, yref = torch.empty_like(x), torch.empty_like(x)
+    stream = torch.cuda.current_stream()
+    LS = _lib.open_library(args.lib)
+    LS.ntt_stamps_set.argtypes = [C.c_void_p, C.c_size_t]
+    LP = _lib.open_library(os.path.join(ROOT, "ntt_aie_amd", "libntt_hip.so"))
+    plans = {}
+    for name, L in (("stamps", LS), ("product", LP)):
+        h = C.c_void_p()
+        assert L.ntt_plan_create(C.byref(h), args.logn, GOLDILOCKS, 8, 0) == 0
+        assert L.ntt_plan_generate_twiddles(h, 0, 7) == 0
+        plans[name] = (L, h)
+    npass = int(LS.ntt_plan_info(plans["stamps"][1], 3))
+    assert npass == 2, "phase_stamps.py stamps two-pass transforms (one record region per pass kind)"
+    stages = [int(LS.ntt_plan_info(plans["stamps"][1], 32 + i)) for i in range(npass)]
+    records = 1 << 18  # two regions of 2^17 wave records (a launch of the headline has 8192 x 4 / 16384 x 4 waves)
+    buf = torch.zeros((records, REC), dtype=torch.int64, device="cuda:0")
+    ms, k = (C.c_float * 8)(), C.c_int(0)
+
+    def fwd(name, out, timed=False):
+        L, h = plans[name]
+        if timed:
+            assert L.ntt_forward_profile(h, x.data_ptr(), out.data_ptr(), args.batch, 0, stream.cuda_stream, ms, 8, C.byref(k)) == 0
+            return [float(ms[i]) for i in range(k.value)]
+        assert L.ntt_forward(h, x.data_ptr(), out.data_ptr(), args.batch, 0, stream.cuda_stream) == 0
+        return None
+
+    for _ in range(6):
+        fwd("product", yref)
+        fwd("stamps", y)
+    torch.cuda.synchronize()
+    # per-pass kernel times, interleaved; here the stamps go to the dummy record (same store count per wave as with a buffer)
+    tp, ts = [], []
+    for _ in range(5):
+        tp.append(fwd("product", yref, True))
+        ts.append(fwd("stamps", y, True))
+    same = bool(torch.equal(y, yref))
+    assert LS.ntt_stamps_set(buf.data_ptr(), records) == 0
+    for _ in range(args.reps):
+        fwd("stamps", y)
+    torch.cuda.synchronize()
+    same = same and bool(torch.equal(y, yref))
+    assert LS.ntt_stamps_set(None, 0) == 0
+    recs = buf.cpu().numpy().view(np.uint64)
+    half = records // 2
+
+    def med(rows, i):
+        return statistics.median(r[i] for r in rows)
+
+    out = {"src_hash": _lib.kernel_source_hash(), "device": torch.cuda.get_device_name(0), "logn": args.logn, "batch": args.batch,
+           "library": os.path.relpath(args.lib, ROOT), "outputs_identical_to_product_library": same,
+           "method": __doc__.split("usage")[0].strip(),
+           "overhead": {"product_pass_ms": [med(tp, i) for i in range(npass)], "stamped_pass_ms": [med(ts, i) for i in range(npass)],
+                        "stamped_over_product": [med(ts, i) / med(tp, i) for i in range(npass)]},
+           "passes": [dict(kind="contig (LDS-DMA, radix-8 rounds 3+3+2)", **reduce_region(recs[:half], 3, True, stages[0], 8, 256)),
+                      dict(kind="column (radix-16 rounds 4+4)", **reduce_region(recs[half:], 2, False, stages[1], 16, 256))]}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+    if not same:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()
