@@ -320,20 +320,30 @@ def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, issue_model=None
     return out
 
 
-def decide_bound(pass_frac_of_copy, valu_frac_of_peak, waves=None):
-    """roofline.bound from the run's own numbers: "hbm" when every pass streams at >= 0.9 of the same-run device copy, "valu" when
-    the vector ALU is at >= 0.9 of its SIMD-32 peak, otherwise neither roofline is saturated and the label says what the counters
-    show instead.  Returns (bound, detail).  Pure arithmetic (CPU unit test)."""
+def decide_bound(pass_frac_of_copy, valu_frac_of_peak, waves=None, held_clock_GHz=None):
+    """roofline.bound from the run's own numbers, never asserted:
+      "hbm"        every pass streams at >= 0.9 of the same-run device copy
+      "valu"       the vector ALU is at >= 0.9 of its SIMD-32 peak at the held clock
+      "power-cap"  neither, and the kernels hold less than 0.9 of the 2.4 GHz peak clock: the board power cap (1400 W) is the
+                   resource that is exhausted -- HBM traffic and VALU work both cost joules, and the clock is what gives
+                   (profiles/rNN_power_probe.txt: the transform draws 1359-1397 W at 1.91-1.94 GHz, its VALU work alone 1132 W at
+                   2.4 GHz, a copy of its bytes alone 1117 W; profiles/r05_ab_contig8w_bound.txt: +49 % resident waves return 2.9 %
+                   of a pass, so it is not per-wave issue latency)
+      "unsaturated" none of the above can be shown (no counters for these sources, or the clock is held): nothing is claimed
+    Returns (bound, detail).  Pure arithmetic (CPU unit test)."""
     hb = min(pass_frac_of_copy) if pass_frac_of_copy else None
     if hb is not None and hb >= 0.9:
         return "hbm", "every pass streams at >= %.2f of the same-run device copy" % hb
     if valu_frac_of_peak is not None and valu_frac_of_peak >= 0.9:
         return "valu", "vector ALU at %.2f of its SIMD-32 peak at the held clock" % valu_frac_of_peak
     w = ("%.1f" % (sum(waves) / len(waves))) if waves and all(waves) else "~4"
-    return ("issue-latency", "neither roofline is saturated: passes stream at %s of the device copy, vector ALU at %s of its SIMD-32 "
-            "peak; what binds is per-wave issue latency at %s waves per SIMD under the board power cap"
-            % ("%.2f" % hb if hb is not None else "n/a", "%.2f" % valu_frac_of_peak if valu_frac_of_peak is not None else "n/a (no counters "
-               "for these sources)", w))
+    what = "passes stream at %s of the device copy, vector ALU at %s of its SIMD-32 peak (%s waves per SIMD)" % (
+        "%.2f" % hb if hb is not None else "n/a", "%.2f" % valu_frac_of_peak if valu_frac_of_peak is not None else "n/a (no counters for these sources)", w)
+    clk = min(held_clock_GHz) if held_clock_GHz and all(held_clock_GHz) else None
+    if clk is not None and clk < 0.9 * PEAK_CLOCK_GHZ:
+        return ("power-cap", "neither roofline is saturated: %s; the kernels hold %.2f of %.1f GHz under the board power cap -- the energy of "
+                "the HBM traffic plus the VALU work is what is exhausted, not either unit" % (what, clk, PEAK_CLOCK_GHZ))
+    return "unsaturated", "neither roofline is saturated: %s; no held-clock figure shows a power cap" % what
 
 
 def load_issue_model(passes, src_hash, waves_per_simd=4):
@@ -626,13 +636,16 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
     step_s = out["ms_per_step"] * 1e-3
     pass_of_copy = [alg_bytes / (float(v) * 1e-3) / 1e9 / copy["GBs"] for v in per_pass]
     vfrac = valu.get("frac_of_peak_at_held_clock") if valu else None
-    bound, bound_detail = decide_bound(pass_of_copy, vfrac, valu.get("mean_waves_per_simd") if valu else None)
+    # the clock the kernels held in THIS run: shader cycles of the profiled launches (counters) over this run's pass durations
+    bound, bound_detail = decide_bound(pass_of_copy, vfrac, valu.get("mean_waves_per_simd") if valu else None,
+                                       valu.get("clock_this_run_GHz_estimate") if valu else None)
     # what this pass count can reach on THIS device: every trip at the rate a plain copy of the same bytes achieves here
     practical_ms = len(passes) * copy["ms"]
     out["roofline"] = {
         # The contract's figure: algorithmic HBM bytes / kernel time against the 8 TB/s spec peak (achieved, peak, unit, frac);
         # `roofline_of_fields` says which roofline those four numbers are.  `bound` is decided from the run's numbers
-        # (decide_bound): "hbm" / "valu" only when that unit is at >= 0.9 of what it can do, otherwise what the counters show.
+        # (decide_bound): "hbm" / "valu" only when that unit is at >= 0.9 of what it can do; "power-cap" when neither is and the
+        # kernels hold less than 0.9 of the peak clock; "unsaturated" when nothing can be shown.
         "bound": bound, "bound_detail": bound_detail, "roofline_of_fields": "hbm",
         "bound_note": "achieved/peak/frac are the HBM roofline SURVEY 8(d) prescribes (algorithmic bytes over the spec peak); "
                       "frac_ceiling is what frac could reach at most with this pass count, frac_of_practical_hbm how close the step is "
@@ -798,7 +811,8 @@ def config_roofline(cfg_key, c, op_ms, copy_ms, passes, src_hash):
                                  "not a throughput limit" % (op_ms * 1e3))
     else:
         bound, why = decide_bound([of_copy] if of_copy else None, valu["frac_of_peak_at_held_clock"] if valu else None,
-                                  [w for w in valu["mean_waves_per_simd"] if w] if valu else None)
+                                  [w for w in valu["mean_waves_per_simd"] if w] if valu else None,
+                                  [h for h in valu["held_clock_GHz"] if h and h < 2.6] if valu else None)
     return {"bound": bound, "bound_detail": why, "roofline_of_fields": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "frac_ceiling": ceiling,
             "traffic": traffic, "traffic_ratio_to_algorithmic": (traffic / alg if traffic else None), "traffic_source": pmc_src,

@@ -131,7 +131,7 @@ struct PlanAlt {
 // modulus classes of the 4-byte-word kernels (pass_kernel.inc picks the instruction stream the same way)
 inline bool m32_lazy_modulus(uint64_t p) { return p < 0x40000000ull; }
 
-// measured crossovers (same process, tools/run_plan_alternatives_r03.sh -> profiles/r03_plan_alternatives.txt):
+// measured crossovers (same process, tools/ab_latency.py; round 3's driver script is in the history -> profiles/r03_plan_alternatives.txt):
 //   8-byte N = 2^13, 7 + 6 -> 13:  batch 1 +23 %, 32 +15 %, 64 +7 %, 128 -7.5 %, 256 -13 %, 2048 -17 %, 65536 -10 % (inverse -6 .. -22 %)
 //   4-byte lazy N = 2^14, 8 + 6 -> 14:  batch 1 +18 %, 32 +8 %, 64 0 %, 128 -15 %, 256 -22 %, 1024..4096 -1 .. -3 %, 65536 -20 % (inverse -1 .. -22 %)
 #ifndef NTT_ALT_MIN_BATCH_GL13
@@ -176,7 +176,7 @@ inline std::vector<PlanAlt> plan_alternatives(int n, int word_bytes, uint64_t p)
         // the same unit runs on 512 threads x 8 words (variant 1: radix-8 rounds, one more LDS exchange) -- twice the waves per
         // polynomial, so a launch of one generation of workgroups issues its butterflies at 2 .. 6 waves per SIMD instead of
         // 1 .. 4 (VOP3 forms issue in 3.4 cycles per wave-instruction at 4 waves per SIMD, 2.0 at 8: profiles/r04_valu_issue_cost.json).
-        // Same-process crossover (tools/run_ab_m32_wide_r04.sh -> profiles/r04_ab_m32_wide.txt).  Alternative 0 = the wide variant,
+        // Same-process crossover (tools/ab_latency.py; round 4's driver script is in the history -> profiles/r04_ab_m32_wide.txt).  Alternative 0 = the wide variant,
         // alternative 1 = the default radix-16 kernel from the threshold on; same stages, same words.
         std::vector<PassDesc> wide = def;
         wide[0].variant = 1;

@@ -149,15 +149,18 @@ def test_valu_roofline_arithmetic_on_a_synthetic_mix():
 
 
 def test_decide_bound_from_the_runs_numbers():
-    """roofline.bound is computed, not asserted: "hbm" / "valu" only at >= 0.9 of that roofline, otherwise what the counters show."""
+    """roofline.bound is computed, not asserted: "hbm" / "valu" only at >= 0.9 of that roofline; "power-cap" when neither is
+    saturated and the kernels hold < 0.9 of the peak clock; "unsaturated" when nothing can be shown."""
     import bench
 
     assert bench.decide_bound([0.95, 0.93], 0.46)[0] == "hbm"
     assert bench.decide_bound([0.88, 0.89], 0.93)[0] == "valu"
-    b, why = bench.decide_bound([0.88, 0.89], 0.46, [3.7, 3.7])
-    assert b == "issue-latency" and "0.88" in why and "0.46" in why and "3.7 waves" in why
+    b, why = bench.decide_bound([0.88, 0.89], 0.46, [3.7, 3.7], [1.95, 1.97])
+    assert b == "power-cap" and "0.88" in why and "0.46" in why and "3.7 waves" in why and "1.95" in why
+    b, why = bench.decide_bound([0.88, 0.89], 0.46, [3.7, 3.7], [2.38, 2.39])  # the clock is held: no cap to blame
+    assert b == "unsaturated"
     b, why = bench.decide_bound([0.88, 0.89], None)
-    assert b == "issue-latency" and "n/a" in why  # no counters for these sources: neither roofline is claimed
+    assert b == "unsaturated" and "n/a" in why  # no counters for these sources: nothing is claimed
     assert bench.decide_bound(None, 0.95)[0] == "valu"
 
 

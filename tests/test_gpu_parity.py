@@ -351,7 +351,7 @@ def test_bench_json_contract():
     # achieved / peak / frac: the HBM roofline of the contract (algorithmic bytes over the 8 TB/s spec peak); `bound` is decided from
     # the run's own numbers (bench.decide_bound: a roofline is named only at >= 0.9 of it), frac_ceiling is what frac can reach
     # with this pass count
-    assert r["bound"] in ("hbm", "valu", "issue-latency") and r["roofline_of_fields"] == "hbm" and r["bound_detail"]
+    assert r["bound"] in ("hbm", "valu", "power-cap", "unsaturated") and r["roofline_of_fields"] == "hbm" and r["bound_detail"]
     assert r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert "configs" not in d  # the extra configurations ride on the default shape only (batch 4096)
     assert r["frac_ceiling"] == pytest.approx(1.0 / r["passes"]) and r["frac"] <= r["frac_ceiling"]

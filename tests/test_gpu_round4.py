@@ -283,7 +283,7 @@ def test_bench_json_contract_frac_step_and_gpu_input_sample():
     assert abs(r["achieved_step"] - r["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9) / r["achieved_step"] < 1e-6
     # the step against what two trips at this run's device-copy rate would take: a fraction of a floor, so below 1 up to clock noise
     assert 0.5 < r["frac_of_practical_hbm"] < 1.05 and abs(r["practical_hbm_floor_ms"] - 2 * r["device_copy"]["ms"]) < 1e-9
-    assert r["bound"] in ("hbm", "valu", "issue-latency") and r["roofline_of_fields"] == "hbm" and r["bound_detail"]
+    assert r["bound"] in ("hbm", "valu", "power-cap", "unsaturated") and r["roofline_of_fields"] == "hbm" and r["bound_detail"]
     if r["valu"] is not None:  # counters of exactly these sources are committed: the re-based figures (SIMD-32: 2 cycles per wave64 instruction)
         v = r["valu"]
         assert v["peak_cycles_per_wave_instr"] == 2.0 and 0 < v["frac_of_peak_at_held_clock"] < 1.0

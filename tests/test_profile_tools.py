@@ -247,3 +247,54 @@ def test_design_md_tables_are_what_the_profiles_say():
     spread = s.split("ms per step** (", 1)[1].split(") |", 1)[0]
     again = dt.replace(dt.replace(s, "headline", dt.headline(spread)), "configs", dt.configs())
     assert again == s
+
+
+def test_phase_stamp_reducer_on_synthetic_records():
+    """tools/phase_stamps.py: [waves][128] records of s_memtime stamps -> per-phase cycle table.  Synthetic records with known
+    phase lengths (LDS-DMA kernel, R = 3: stamps 0..9 per iteration; column kernel, R = 2: no stamp 1): steady-state iterations
+    are averaged apart from iteration 0, shares sum to 1, the clock comes from the s_memrealtime pair (100 MHz)."""
+    import numpy as np
+
+    import phase_stamps as ps
+
+    R, nst = 3, 10
+    lens = [120, 600, 2800, 550, 2750, 430, 1650, 300, 100]  # stamp k-1 -> k, k = 1..9
+    recs = np.zeros((6, 128), dtype=np.uint64)
+    for w in range(4):  # two records stay empty (slot 1 == 0): not sampled
+        r = recs[w]
+        r[0], r[1], r[3] = 1000, 50000, 3
+        t = 50000 + 3000  # init
+        for it in range(3):
+            scale = 2 if it == 0 else 1  # a cold first iteration
+            r[4 + it * 12] = t
+            for k in range(1, nst):
+                t += lens[k - 1] * scale
+                r[4 + it * 12 + k] = t
+            t += 250  # loop back
+        r[126] = t
+        r[127] = 1000 + (t - 50000) // 20  # 100 MHz ticks at 2.0 GHz
+    o = ps.reduce_region(recs, R, True, 8, 8, 256)
+    assert o["waves_sampled"] == 4 and o["clock_GHz_median"] == pytest.approx(2.0, rel=1e-3) and o["init_cycles_median"] == 3000
+    assert [p["cycles_mean"] for p in o["phases"]] == [pytest.approx(v) for v in lens + [250]]
+    assert o["phases"][2]["cycles_mean_iteration0"] == pytest.approx(5600)
+    assert o["iteration_cycles_mean_steady"] == pytest.approx(sum(lens) + 250)
+    assert sum(p["share_of_iteration"] for p in o["phases"]) == pytest.approx(1.0)
+    assert o["split"]["compute (register rounds)"]["cycles"] == pytest.approx(2800 + 2750 + 1650)
+    assert o["split"]["exchange (LDS)"]["cycles"] == pytest.approx(550 + 430)
+    assert o["wave_butterflies_per_iteration"] == 32 and o["wave_elapsed_cycles_per_wave_butterfly"] == pytest.approx((sum(lens) + 250) / 32)
+    # a kernel without an LDS-DMA tile writes no stamp 1: its load phase runs from stamp 0 to stamp 2
+    recs2 = np.zeros((2, 128), dtype=np.uint64)
+    r = recs2[0]
+    r[0], r[1], r[3] = 10, 1000, 2
+    t = 2000
+    for it in range(2):
+        for k in range(8):
+            if k != 1:
+                r[4 + it * 12 + k] = t
+            t += 100
+        t += 40
+    r[126], r[127] = t, 10 + (t - 1000) // 24
+    o2 = ps.reduce_region(recs2, 2, False, 8, 16, 256)
+    assert [p["ends_at_stamp"] for p in o2["phases"]] == [2, 3, 4, 5, 6, 7, 0]
+    assert o2["phases"][0]["cycles_mean"] == pytest.approx(200) and o2["phases"][-1]["cycles_mean"] == pytest.approx(140)
+    assert ps.reduce_region(np.zeros((3, 128), dtype=np.uint64), 2, False, 8, 16, 256)["waves_sampled"] == 0

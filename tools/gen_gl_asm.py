@@ -38,13 +38,13 @@ def is_sgpr(r):
     return r.startswith("s") or r == "vcc"
 
 
-def butterfly(kind, b, vbase=104):
+def butterfly(kind, b, vbase=104, sbase=80):
     """Instruction list of butterfly `b` (0/1).  kind: 'fwd' | 'inv' | 'mul'.
     Operand names: x0 x1 y0 y1 t0 t1 (compiler operands, suffixed by b), temporaries
     d0 d1 (operands), fixed pairs L M A B H Z, SGPR pairs sa sb se sf."""
     vb = vbase + 12 * b
     L, M, A, B, H, Z = [(f"v{vb + 2 * i}", f"v{vb + 2 * i + 1}") for i in range(6)]
-    sb_ = 80 + 10 * b
+    sb_ = sbase + 10 * b
     sa, sbb, se, sf, s5 = [f"s[{sb_ + 2 * i}:{sb_ + 2 * i + 1}]" for i in range(5)]  # s5: the product's sign while its fix-up is computed
 
     def P(pair):
@@ -509,8 +509,8 @@ def schedule(lists):
     return out
 
 
-def emit(kind, nb, tw_constraint, vbase=104, suffix=""):
-    lists = [butterfly(kind, b, vbase) for b in range(nb)]
+def emit(kind, nb, tw_constraint, vbase=104, suffix="", sbase=80):
+    lists = [butterfly(kind, b, vbase, sbase) for b in range(nb)]
     lines = schedule(lists)
     nops = sum(1 for l in lines if l.startswith("s_nop"))
     name = f"gl_{kind}{nb}_{'s' if tw_constraint == 's' else 'v'}{suffix}"
@@ -554,7 +554,7 @@ def emit(kind, nb, tw_constraint, vbase=104, suffix=""):
     if kind == "invs":
         ins_ += ['[c0] "s"(c0)', '[c1] "s"(c1)']
     ins_ += [f'[zero_{b}] "v"(zero_{b})' for b in range(nb)]
-    clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 12 * nb) if r not in zero_regs] + [f'"s{r}"' for r in range(80, 80 + 10 * nb)]
+    clob = ['"vcc"', '"scc"'] + [f'"v{r}"' for r in range(vbase, vbase + 12 * nb) if r not in zero_regs] + [f'"s{r}"' for r in range(sbase, sbase + 10 * nb)]
     src.append("        : " + ", ".join(outs))
     src.append("        : " + ", ".join(ins_))
     src.append("        : " + ", ".join(clob) + ");")
@@ -653,6 +653,10 @@ def main():
         if kind != "mul":
             for tw in ("v", "s"):  # for the radix-8 (light) kernels: scratch lives lower
                 txt, n, nops = emit(kind, 2, tw, vbase=72, suffix="_lo")
+                out.append(txt)
+                out.append("")
+            if os.environ.get("NTT_GEN_W") and kind == "fwd":  # EXPERIMENT (r05 8-wave bound): scratch at v[40:63] for a 64-VGPR kernel
+                txt, n, nops = emit(kind, 2, "v", vbase=40, suffix="_w", sbase=int(os.environ.get("NTT_GEN_W_SBASE", "50")))
                 out.append(txt)
                 out.append("")
     for kind in ("fwd32", "inv32", "mul32"):

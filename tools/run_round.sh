@@ -31,6 +31,10 @@ profiles)
     echo; echo "# the same kernels with L2-resident loads and no stores (ntt_plan_set_debug(3)): the VALU floor"; python3 tools/sq_table.py $(find gpurun_out/sq_floor -name '*counter_collection.csv' | head -1); } > $S/${TAG}_sq_real_vs_floor.txt
   cat $S/${TAG}_sq_real_vs_floor.txt
   rm -rf gpurun_out/sq_real gpurun_out/sq_floor
+  # where the cycles of the two headline kernels go (diagnostic side build with s_memtime stamps, built HERE: tools/ab_build.sh stamps -DNTT_PHASE_STAMPS)
+  if [ -f ab/libntt_stamps.so ]; then timeout -k 10 300 python3 tools/phase_stamps.py > $S/${TAG}_phase_stamps.json 2> gpurun_out/stamps.err || tail -3 gpurun_out/stamps.err; fi
+  # the butterfly statement against occupancy, 1 .. 8 waves per SIMD (tools/stream_occupancy.hip, built HERE)
+  if [ -x tools/stream_occupancy ]; then timeout -k 10 200 tools/stream_occupancy > $S/${TAG}_stream_occupancy.txt 2>&1 || true; fi
   python3 tools/bench_configs.py > $S/${TAG}_bench_all_configs.jsonl 2> gpurun_out/cfg.err || true
   python3 tools/bench_m64.py > $S/${TAG}_bench_m64.jsonl 2>> gpurun_out/cfg.err || true
   NTT_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --single-process --no-cpu-baseline --no-valu-floor > $S/${TAG}_bench_single_process_rehearsal.json 2>> gpurun_out/cfg.err || true

@@ -1,0 +1,105 @@
+// stream_occupancy.hip -- the forward Goldilocks butterfly stream (two butterflies per statement: csrc/gl_asm.h) as a register-resident
+// radix-8 round, at 1 .. 8 waves per SIMD.  tools/valu_issue_cost.hip measures the streams only up to 4 waves (its kernels pin
+// v104+); here the statement's scratch lives at v[40:63] and its carries in s[50:69] (tools/gen_gl_asm.py with NTT_GEN_W=1 ->
+// ab/gl_asm_w.h: gl_fwd2_v_w), so the kernel fits 64 VGPRs and 8 waves share a SIMD.  Question (round 5): does the stream itself
+// speed up with occupancy the way its single instruction forms do (3.35 -> 1.99 cycles between 4 and 8 waves)?
+// build: NTT_GEN_W=1 python3 tools/gen_gl_asm.py ab/gl_asm_w.h && hipcc -O3 --offload-arch=gfx950 -I ab tools/stream_occupancy.hip -o tools/stream_occupancy
+// run:   tools/stream_occupancy   (text on stdout)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "gl_asm_w.h"
+
+constexpr int ITERS = 1500;
+constexpr int CUS = 256;
+
+struct Stamp {
+    unsigned long long cycles, ticks;
+};
+
+template <int MODE>  // 0: the stream as shipped (22 VALU + 5 SALU per butterfly); 1: two rounds' worth of independent data per iteration (16 words: more statements in flight per wave is NOT possible with one scratch set -- kept for symmetry: same as 0 on words 8..15)
+__global__ void __launch_bounds__(256, 8) k_round8(uint32_t *out, Stamp *st, int iters, uint32_t seed) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using namespace ntt;
+    const uint64_t P = 0xFFFFFFFF00000001ull;
+    uint64_t a[8], t[7];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = ((uint64_t) (threadIdx.x * 2654435761u + seed * (i + 3)) << 21 | (i * 1315423911u)) % P;
+#pragma unroll
+    for (int i = 0; i < 7; i++) t[i] = ((((uint64_t) (seed * 40503u + i * 97u) << 29) | (i * 2246822519u + seed)) + threadIdx.x) % P;
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 3; s++) {
+            const int h = 1 << s;
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+                const int j0 = ((q >> s) << (s + 1)) | (q & (h - 1));
+                const int j1 = (((q + 1) >> s) << (s + 1)) | ((q + 1) & (h - 1));
+                const uint64_t t0 = t[(4 >> s) - 1 + (j0 >> (s + 1))], t1 = t[(4 >> s) - 1 + (j1 >> (s + 1))];
+                gl_fwd2_v_w(a[j0], a[j0 + h], t0, a[j1], a[j1 + h], t1);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    if ((threadIdx.x & 63) == 0) st[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = Stamp{c1 - c0, r1 - r0};
+    uint64_t x = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) x ^= a[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t) (x ^ (x >> 32));
+#endif
+}
+
+int main() {
+    uint32_t *d_out;
+    Stamp *d_st;
+    const size_t max_threads = (size_t) CUS * 8 * 256;
+    hipMalloc(&d_out, max_threads * sizeof(uint32_t));
+    hipMalloc(&d_st, max_threads / 64 * sizeof(Stamp));
+    std::vector<Stamp> h(max_threads / 64);
+    auto kern = k_round8<0>;
+    hipFuncAttributes fa;
+    hipFuncGetAttributes(&fa, (const void *) kern);
+    printf("# gl_fwd2_v_w as a register-resident radix-8 round (12 butterflies per iteration, %d iterations); kernel: %d VGPRs, %d SGPRs\n", ITERS, fa.numRegs, 0);
+    printf("# waves/SIMD  cycles per butterfly per SIMD  cycles per VALU instruction (22)  clock GHz\n");
+    for (int w = 1; w <= 8; w++) {
+        const int blocks = CUS * w;
+        const size_t lds = (160 * 1024 / w) - 512;
+        if (hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) return 1;
+        for (int k = 0; k < 2; k++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_out, d_st, ITERS, 12345u + k);
+        hipDeviceSynchronize();
+        std::vector<double> cyc, ghz;
+        for (int r = 0; r < 5; r++) {
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_out, d_st, ITERS, 777u + r);
+            hipDeviceSynchronize();
+            const size_t nw = (size_t) blocks * 4;
+            hipMemcpy(h.data(), d_st, nw * sizeof(Stamp), hipMemcpyDeviceToHost);
+            std::vector<unsigned long long> c(nw), t(nw);
+            for (size_t i = 0; i < nw; i++) c[i] = h[i].cycles, t[i] = h[i].ticks;
+            std::nth_element(c.begin(), c.begin() + nw / 2, c.end());
+            std::nth_element(t.begin(), t.begin() + nw / 2, t.end());
+            cyc.push_back((double) c[nw / 2]);
+            ghz.push_back((double) c[nw / 2] / ((double) t[nw / 2] * 10.0));
+        }
+        if (hipGetLastError() != hipSuccess) return 2;
+        std::sort(cyc.begin(), cyc.end());
+        std::sort(ghz.begin(), ghz.end());
+        const double per_bf = cyc[2] / (w * 12.0 * ITERS);
+        printf("%d  %.2f  %.3f  %.3f\n", w, per_bf, per_bf / 22.0, ghz[2]);
+        fflush(stdout);
+    }
+    return 0;
+}
