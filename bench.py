@@ -40,7 +40,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from hw import HBM_PEAK_GBS, PEAK_CLOCK_GHZ, SIMDS, VALU_PEAK_CYCLES_PER_WAVE_INSTR  # noqa: E402  (tools/hw.py: the one place the peaks live)
 
 SEED = 0x9E3779B97F4A7C15  # a[b][i] = splitmix64(SEED + b*N + i) mod p
-PROFILE_ROUND = "r04"  # the collection DESIGN.md section 4 is generated from (tools/design_table.py); counters are quoted from the newest matching round (tagged_profile)
+PROFILE_ROUND = "r05"  # the collection DESIGN.md section 4 is generated from (tools/design_table.py); counters are quoted from the newest matching round (tagged_profile)
 
 
 def _s64(v: int) -> int:
@@ -636,9 +636,10 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
     step_s = out["ms_per_step"] * 1e-3
     pass_of_copy = [alg_bytes / (float(v) * 1e-3) / 1e9 / copy["GBs"] for v in per_pass]
     vfrac = valu.get("frac_of_peak_at_held_clock") if valu else None
-    # the clock the kernels held in THIS run: shader cycles of the profiled launches (counters) over this run's pass durations
+    # the clock the kernels hold: GRBM_GUI_ACTIVE / 8 / duration of the profiled launches (a measurement; clock_this_run_GHz_estimate,
+    # the same cycles over THIS run's durations, is reported beside it)
     bound, bound_detail = decide_bound(pass_of_copy, vfrac, valu.get("mean_waves_per_simd") if valu else None,
-                                       valu.get("clock_this_run_GHz_estimate") if valu else None)
+                                       valu.get("held_clock_GHz") if valu else None)
     # what this pass count can reach on THIS device: every trip at the rate a plain copy of the same bytes achieves here
     practical_ms = len(passes) * copy["ms"]
     out["roofline"] = {

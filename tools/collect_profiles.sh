@@ -42,10 +42,7 @@ rocprofv3 --pmc $SQCNT \
 echo "sq done"
 S=$(find "$OUT/sq" -name '*counter_collection.csv' | head -1)
 python3 $ROOT/tools/sq_summary.py "$S" > "$SUM/${TAG}_sq_counters.json"
-# the judged bench line once more, now that the counter summaries of THIS build exist: bench.py quotes roofline.traffic and the VALU
-# counters only from profiles/<tag>_*.json stamped with the tree's kernel-source hash
 cp "$SUM/${TAG}_pmc_traffic.json" "$SUM/${TAG}_sq_counters.json" "$ROOT/profiles/"
-python3 $ROOT/bench.py > "$SUM/${TAG}_bench.json"
 head -c 1500 "$SUM/${TAG}_pmc_traffic.json"; echo
 # ---- the other BASELINE configurations under the same standard: per-kernel durations, HBM bytes, SQ counters per OPERATION ----
 collect_config() {  # $1 = config key of tools/configs.py, $2 = reps under --stats, $3 = reps under --pmc (kernels are serialised there)
@@ -64,4 +61,9 @@ collect_config() {  # $1 = config key of tools/configs.py, $2 = reps under --sta
 collect_config cfg2 200 20
 collect_config cfg2_sat 20 5
 collect_config cfg4 10 3
+# the judged bench line once more, now that the counter summaries of THIS build exist (headline AND configs 2 / 4): bench.py quotes
+# roofline.traffic and the VALU counters only from profiles/<tag>_*.json stamped with the tree's kernel-source hash
+cd /tmp
+python3 $ROOT/bench.py > "$SUM/${TAG}_bench.json"
+tail -c 300 "$SUM/${TAG}_bench.json"; echo
 ls -la "$SUM"

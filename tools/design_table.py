@@ -49,72 +49,88 @@ def headline(spread):
     pa, ca = power("forward (L2 loads, no stores)", pp)
     pc, _ = power("copy (xor kernel)", pp)
     cb = d["cpu_baseline"]
-    w = v.get("frac_at_held_clock_weighted")
-    im = v.get("issue_model") or {}
-    cc = im.get("class_cycles", {})
+    ic = v.get("issue_cost_at_kernel_occupancy") or {}
+    cc = ic.get("class_cycles", {})
     rk = d["ranks"][0]
-    return """| quantity (`profiles/{R}_bench.json`, `{R}_kernel_stats.csv`, `{R}_pmc_traffic.json`, `{R}_sq_counters.json`) | value |
+    ps = json.load(open(P("%s_phase_stamps.json" % R)))
+    sp = [p["split"] for p in ps["passes"]]
+
+    def share(i, key):
+        return 100 * next(v_["share"] for k_, v_ in sp[i].items() if k_.startswith(key))
+
+    return """| quantity (`profiles/{R}_bench.json`, `{R}_kernel_stats.csv`, `{R}_pmc_traffic.json`, `{R}_sq_counters.json`, `{R}_phase_stamps.json`) | value |
 |---|---|
 | throughput | **{val:.2f} M NTT/s = {bf:.2f}e12 butterflies/s, {ms:.3f} ms per step** ({spread}) |
 | verification in the same run | rank 0 on `{bus}`: inverse(forward(x)) == x over the whole shard, out[b][0] == Σ a[b][:] mod p on {rows} rows: `all_ranks_verified` {ver} |
 | pass kernels, hipEvents / rocprofv3 | CONTIG {p0:.3f} / {k0:.3f} ms, column {p1:.3f} / {k1:.3f} ms |
-| `roofline.achieved / peak / frac` (contract: algorithmic bytes over 8 TB/s) | {ach:.2f} TB/s / 8 TB/s = **{frac:.3f}**; `frac_step` (over the line's own `ms_per_step`) {fs:.3f}; `frac_ceiling` 0.5 (two passes) |
+| `roofline.achieved / peak / frac` (contract: algorithmic bytes over 8 TB/s) | {ach:.2f} TB/s / 8 TB/s = **{frac:.3f}**; `frac_step` (over the line's own `ms_per_step`, not clamped) {fs:.3f}; `frac_ceiling` 0.5 (two passes) |
+| `frac_of_practical_hbm` | two trips at the same-run device-copy rate ({cp:.2f} TB/s) would take {pf:.3f} ms: the step is at **{fp:.2f}** of that |
 | `roofline.traffic` (PMC, forward kernels) | {tr:.3f} GB = {trr:.2f} × algorithmic: two trips, no over-fetch within a pass |
-| each pass's stream rate | {s0:.2f} / {s1:.2f} TB/s = {f0:.2f}–{f1:.2f} of peak = {c0:.2f}–{c1:.2f} of the same-process device copy ({cp:.2f} TB/s) |
-| **`roofline.bound` = `valu`**, flat price (every VALU form 4 cycles) | {ipb:.2f} VALU per butterfly ({i0:.2f} / {i1:.2f}); peak = 1024 SIMDs·f/(4·instr)·64 = {pk:.2f}e12 bf/s at 2.4 GHz; frac {f24:.2f} at 2.4 GHz, {fh:.2f} at the held clock ({h0:.2f}–{h1:.2f} GHz under the counter run) |
-| … priced with **measured issue costs** (`{R}_valu_issue_cost.json` at 4 waves per SIMD, `{R}_valu_mix.json`) | carry / compare / `v_mad_u64_u32` forms {cy:.2f} cycles per wave-instruction, plain moves {pl:.2f}; a butterfly {w0:.1f} / {w1:.1f} cycles ⇒ **{w:.2f} of the issue capacity at the held clock** ({wv}) |
-| what holds the clock | the 1400 W board cap: transform {pt:.0f} W at {ct:.2f} GHz; arithmetic alone {pa:.0f} W at {ca:.2f} GHz; copy alone {pc:.0f} W (`profiles/{R}_power_probe.txt`) |
+| each pass's stream rate | {s0:.2f} / {s1:.2f} TB/s = {f0:.2f}–{f1:.2f} of peak = {c0:.2f}–{c1:.2f} of the same-process device copy |
+| `roofline.valu`: vector ALU on the **SIMD-32 peak** (a wave64 instruction = 2 cycles, `tools/hw.py`) | {ipb:.2f} VALU per butterfly ({i0:.2f} / {i1:.2f}); peak = 1024 SIMDs·f/(2·instr)·64 = {pk:.2f}e12 bf/s at 2.4 GHz; `frac_of_peak_at_held_clock` **{fh0:.2f} / {fh1:.2f}** per pass ({kc0:.1f} / {kc1:.1f} kernel cycles per wave-butterfly per SIMD, {h0:.2f}–{h1:.2f} GHz under the counter run, {w0:.1f} / {w1:.1f} waves per SIMD); {f24:.2f} at 2.4 GHz |
+| … the same instructions at the **issue cost of this occupancy** (`issue_cost_at_kernel_occupancy`: `{R}_valu_issue_cost.json` at 4 waves per SIMD, `{R}_valu_mix.json`; a property of the occupancy, never a peak) | VOP3 carry / compare / `v_mad_u64_u32` forms {cy:.2f} cycles per wave-instruction, plain moves {pl:.2f}; a butterfly {ic0:.1f} / {ic1:.1f} cycles ⇒ {icf:.2f} of the kernels' cycles |
+| **`roofline.bound` = `{bound}`** (decided by `bench.decide_bound` from these numbers) | {bd} |
+| what holds the clock | the 1400 W board cap: transform {pt:.0f} W at {ct:.2f} GHz; its VALU work alone (loads from L2, no stores) {pa:.0f} W at {ca:.2f} GHz; a copy of its bytes alone {pc:.0f} W (`profiles/{R}_power_probe.txt`) |
 | VALU floor (same kernels, loads from L2, no stores; measured in the bench run) | {fl0:.3f} + {fl1:.3f} ms (cycle view: `{R}_sq_real_vs_floor.txt`) |
-| CPU baseline (oracle port, same run, **the GPU's own input rows**) | {c1t:.0f} NTT/s on 1 thread; {call:.2f} k on the {cores} cores the box's cgroup quota allows (affinity mask {aff}); {crows} rows |
+| where a wave's cycles go (s_memtime stamps at every phase boundary, diagnostic build; stamping costs +{so0:.0f} % / +{so1:.0f} %) | CONTIG: butterfly rounds {a0:.0f} %, LDS exchanges {b0:.0f} %, tile wait + prefetch issue + stores {c0_:.0f} %, sync + loop {d0:.0f} % of a steady-state iteration ({it0:.0f} cycles for 32 wave-butterflies); column: {a1:.0f} % / {b1:.0f} % / {c1_:.0f} % (its loads are not prefetched) / {d1:.0f} % ({it1:.0f} cycles for 64) |
+| CPU baseline (oracle port, same run, **the GPU's own input rows, never beyond the batch**) | {c1t:.0f} NTT/s on 1 thread; {call:.2f} k on the {cores} cores the box's cgroup quota allows (affinity mask {aff}); {crows} rows |
 | inverse (config 3's second leg) | {inv:.2f} ms, {invr:.3f} × forward, round trip identical |
 """.format(R=R, val=d["value"] / 1e6, bf=d["butterflies_per_s"] / 1e12, ms=d["ms_per_step"], spread=spread,
            bus=rk.get("pci_bus_id") or rk.get("uuid"), rows=rk["rows_sampled"], ver=str(d["all_ranks_verified"]).lower(),
            p0=r["pass_ms"][0], k0=k0, p1=r["pass_ms"][1], k1=k1, ach=r["achieved"] / 1e3, frac=r["frac"], fs=r["frac_step"],
+           pf=r["practical_hbm_floor_ms"], fp=r["frac_of_practical_hbm"],
            tr=r["traffic"] / 1e9, trr=r["traffic"] / r["algorithmic_bytes_per_launch"],
            s0=r["pass_stream_GBs"][0] / 1e3, s1=r["pass_stream_GBs"][1] / 1e3, f0=min(r["pass_stream_frac"]), f1=max(r["pass_stream_frac"]),
            c0=min(r["pass_stream_frac_of_device_copy"]), c1=max(r["pass_stream_frac_of_device_copy"]), cp=r["device_copy"]["GBs"] / 1e3,
            ipb=v["instr_per_butterfly_mean"], i0=v["instr_per_butterfly"][0], i1=v["instr_per_butterfly"][1],
-           pk=v["peak_butterflies_per_s"] / 1e12, f24=v["frac_at_2.4GHz"], fh=v["frac_at_held_clock"],
-           h0=min(v["held_clock_GHz"]), h1=max(v["held_clock_GHz"]),
+           pk=v["peak_butterflies_per_s"] / 1e12, f24=v["frac_of_peak_at_2.4GHz"],
+           fh0=v["frac_of_peak_at_held_clock_per_pass"][0], fh1=v["frac_of_peak_at_held_clock_per_pass"][1],
+           kc0=v["kernel_cycles_per_wave_butterfly_per_simd"][0], kc1=v["kernel_cycles_per_wave_butterfly_per_simd"][1],
+           h0=min(v["held_clock_GHz"]), h1=max(v["held_clock_GHz"]), w0=v["mean_waves_per_simd"][0], w1=v["mean_waves_per_simd"][1],
            cy=cc.get("carry", float("nan")), pl=cc.get("plain", float("nan")),
-           w0=(v.get("issue_cycles_per_butterfly_weighted") or [float("nan")] * 2)[0],
-           w1=(v.get("issue_cycles_per_butterfly_weighted") or [float("nan")] * 2)[1],
-           w=w if w is not None else float("nan"), wv="saturated" if v.get("saturated") else "not saturated: see the reading below",
+           ic0=(ic.get("cycles_per_butterfly") or [float("nan")] * 2)[0], ic1=(ic.get("cycles_per_butterfly") or [float("nan")] * 2)[1],
+           icf=ic.get("frac_of_kernel_cycles", float("nan")), bound=r["bound"], bd=r["bound_detail"],
            pt=pt, ct=ct, pa=pa, ca=ca, pc=pc, fl0=r["valu_floor_pass_ms"][0], fl1=r["valu_floor_pass_ms"][1],
+           so0=100 * (ps["overhead"]["stamped_over_product"][0] - 1), so1=100 * (ps["overhead"]["stamped_over_product"][1] - 1),
+           a0=share(0, "compute"), b0=share(0, "exchange"), c0_=share(0, "memory"), d0=share(0, "sync"), it0=ps["passes"][0]["iteration_cycles_mean_steady"],
+           a1=share(1, "compute"), b1=share(1, "exchange"), c1_=share(1, "memory"), d1=share(1, "sync"), it1=ps["passes"][1]["iteration_cycles_mean_steady"],
            c1t=cb["value_1thread"], call=cb["value"] / 1e3, cores=cb["cores"], aff=cb["host_affinity_cores"], crows=cb.get("sample_rows", 0),
            inv=d["inverse"]["ms_per_step_median"], invr=d["inverse"]["vs_forward_median"])
 
 
 def configs():
-    """configs 2 / 3 / 4: one row each, the same columns."""
+    """configs 2 / 3 / 4: one row each, the same columns.  Configs 2 and 4 are the entries of the SAME driver-run line as the headline
+    (bench.py's `configs` key); config 2 at a saturating batch comes from tools/bench_configs.py."""
     rows = {c["config"].split(":")[0]: c for c in jl(P("%s_bench_all_configs.jsonl" % R))}
     head = jl(P("%s_bench.json" % R))[-1]
-    out = ["| config | time per operation | `frac` of 8 TB/s (ceiling) | HBM bytes, PMC (÷ algorithmic) | VALU per butterfly; ×4 cycles ÷ kernel cycles | "
-           "waves / SIMD; held clock | binds |", "|---|---|---|---|---|---|---|"]
+    line = {e["key"]: e for e in head["configs"]}
+    out = ["| config | time per operation | `frac` of 8 TB/s (ceiling) | HBM bytes, PMC (÷ algorithmic) | VALU per butterfly; × 2 cycles ÷ kernel cycles (SIMD-32 peak) | "
+           "waves / SIMD; held clock | `bound` | verified in the line |", "|---|---|---|---|---|---|---|---|"]
 
-    def row(name, c, extra=""):
-        r = c["roofline"]
+    def row(name, t, r, verified):
         v = r.get("valu") or {}
-        ks = list((v.get("kernels") or {}).values())
-        wav = " / ".join("%.1f" % k["mean_waves_per_simd"] for k in ks if k.get("mean_waves_per_simd"))
-        clk = " / ".join("%.2f" % k["held_clock_GHz"] for k in ks if k.get("held_clock_GHz") and k["held_clock_GHz"] < 2.6)
-        t = c.get("polymul_ms") or c["forward_ms"]
-        return "| %s | %s | %.3f (%.2f) | %s | %s | %s | **%s**: %s%s |" % (
+        wav = " / ".join("%.1f" % w for w in (v.get("mean_waves_per_simd") or []) if w)
+        clk = " / ".join("%.2f" % h for h in (v.get("held_clock_GHz") or []) if h and h < 2.6)
+        return "| %s | %s | %.3f (%.2f) | %s | %s | %s | **%s**: %s | %s |" % (
             name, ("%.1f µs" % (t * 1e3)) if t < 0.1 else ("%.3f ms" % t), r["frac"], r["frac_ceiling"],
             ("%.3f GB (%.3f)" % (r["traffic"] / 1e9, r["traffic_ratio_to_algorithmic"])) if r.get("traffic") else "not quoted",
-            ("%.2f; %.2f" % (v["instr_per_butterfly"], v["frac_at_held_clock"])) if v else "not quoted",
-            ("%s; %s GHz" % (wav, clk or "n/a (launch too short for the counter quotient)")) if v else "—", r["bound"], r["bound_evidence"], extra)
+            ("%.2f; %.2f" % (v["instr_per_butterfly"], v["frac_of_peak_at_held_clock"])) if v else "not quoted",
+            ("%s; %s GHz" % (wav, clk or "n/a (launch too short for the counter quotient)")) if v else "—", r["bound"], r["bound_detail"], verified)
 
-    out.append(row("2: N = 2^12, 32-bit prime, batch 1024 (`%s_cfg2_*`)" % R, rows["cfg2"]))
-    out.append(row("2 at a saturating batch (65536) (`%s_cfg2_sat_*`)" % R, rows["cfg2c"]))
+    def ver(e):
+        return "; ".join("%s %s" % (k, str(v_).lower()) for k, v_ in e["verification"].items() if isinstance(v_, bool))
+
+    e2, e4 = line["cfg2"], line["cfg4"]
+    out.append(row("2: N = 2^12, 32-bit prime, batch 1024 (`%s_bench.json: configs[0]`, `%s_cfg2_*`)" % (R, R), e2["ms"], e2["roofline"], ver(e2)))
+    c2s = rows["cfg2c"]
+    out.append(row("2 at a saturating batch (65536) (`%s_bench_all_configs.jsonl`, `%s_cfg2_sat_*`)" % (R, R), c2s["forward_ms"], c2s["roofline"], "tools/bench_configs.py (not in the line)"))
     hr, hv = head["roofline"], head["roofline"]["valu"]
-    sq = json.load(open(P("%s_sq_counters.json" % R)))
-    waves = " / ".join("%.1f" % sq["kernels"][k]["mean_waves_per_simd"] for k in hv["kernels"])
     out.append("| 3: N = 2^16, Goldilocks, batch 4096 = the headline (`%s_bench.json`) | %.3f ms | %.3f (0.50) | %.3f GB (%.3f) | %.2f; %.2f | %s; %s GHz | "
-               "**valu**: the table above |" % (R, head["ms_per_step"], hr["frac"], hr["traffic"] / 1e9, hr["traffic"] / hr["algorithmic_bytes_per_launch"],
-                                                hv["instr_per_butterfly_mean"], hv["frac_at_held_clock"], waves,
-                                                " / ".join("%.2f" % h for h in hv["held_clock_GHz"])))
-    out.append(row("4: N = 2^20 negacyclic product, Goldilocks, batch 512, 9 N convention (`%s_cfg4_*`)" % R, rows["cfg4"]))
+               "**%s**: the table above | round trip + coefficient sum, every rank |" % (
+                   R, head["ms_per_step"], hr["frac"], hr["traffic"] / 1e9, hr["traffic"] / hr["algorithmic_bytes_per_launch"],
+                   hv["instr_per_butterfly_mean"], hv["frac_of_peak_at_held_clock"], " / ".join("%.1f" % w for w in hv["mean_waves_per_simd"]),
+                   " / ".join("%.2f" % h for h in hv["held_clock_GHz"]), hr["bound"]))
+    out.append(row("4: N = 2^20 negacyclic product, Goldilocks, batch 512, 9 N convention (`%s_bench.json: configs[1]`, `%s_cfg4_*`)" % (R, R), e4["ms"], e4["roofline"], ver(e4)))
     return "\n".join(out) + "\n"
 
 
