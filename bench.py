@@ -716,9 +716,7 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
     code = 0
     if world == 1 and headline and not args.no_configs:
         out["configs"] = extra_configs(torch, stream, src_hash, steps=max(5, min(args.steps, 20)))
-        out["configs_all_verified"] = all(e.get("verified") for e in out["configs"])
-        if any(not e.get("verified") and "error" not in e for e in out["configs"]):
-            code = 1
+        out["configs_all_verified"], code = configs_verdict(out["configs"])
     return code
 
 
@@ -912,6 +910,15 @@ def run_config(torch, key, stream, src_hash, steps):
                   "roofline": config_roofline(key, c, op_ms, copy_ms, npass, src_hash)})
     plan.close()
     return entry
+
+
+def configs_verdict(entries):
+    """(every entry verified?, exit code).  An entry whose result was compared and found WRONG makes the exit code 1 (no time
+    without a check); an entry that could not run at all (an exception: reported with its error, counted as not verified) does
+    not -- the headline's own numbers stand and the line says which leg failed.  Pure (CPU unit test)."""
+    all_ok = all(bool(e.get("verified")) for e in entries)
+    wrong = any((not e.get("verified")) and "error" not in e for e in entries)
+    return all_ok, (1 if wrong else 0)
 
 
 def extra_configs(torch, stream, src_hash, steps=10):

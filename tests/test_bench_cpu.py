@@ -206,6 +206,18 @@ def test_synthetic_generators_and_config_checks(oracle):
     assert bench.poly_eval_mod(cv, r, P) != bench.poly_eval_mod(a, r, P) * bench.poly_eval_mod(b, r, P) % P
 
 
+def test_configs_verdict_wrong_result_is_red_failed_leg_is_reported():
+    """BASELINE configs 2 and 4 in the driver-run line: a WRONG result turns the exit code red; a leg that could not run is
+    reported (not verified, with its error) without taking the headline down."""
+    import bench
+
+    ok = {"key": "cfg2", "verified": True}
+    assert bench.configs_verdict([ok, dict(ok, key="cfg4")]) == (True, 0)
+    assert bench.configs_verdict([ok, {"key": "cfg4", "verified": False, "verification": {"evaluation_at_root_of_xN_plus_1": False}}]) == (False, 1)
+    assert bench.configs_verdict([ok, {"key": "cfg4", "verified": False, "error": "OutOfMemoryError()"}]) == (False, 0)
+    assert bench.configs_verdict([]) == (True, 0)
+
+
 def test_tagged_profile_picks_the_newest_collection_on_these_sources(tmp_path, monkeypatch):
     """Counters are quoted from the newest profiles/rNN_<name>.json whose stamped kernel-source hash equals the tree's -- an older
     round's file when this round did not touch the kernels, nothing at all when no file matches."""
