@@ -1065,6 +1065,10 @@ def main():
     # NTT_BENCH_BACKEND=gloo replaces RCCL, which refuses two ranks on one device
     if os.environ.get("NTT_BENCH_ONE_DEVICE") == "1":
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() == 1:
+        # a launcher that gives every rank its OWN visible device (ROCR_/HIP_VISIBLE_DEVICES per rank): device 0 of this process.
+        # Ranks that in fact share one GPU are caught below: the line is verified only on `world` distinct PCI ids.
+        local_rank = 0
     elif local_rank >= torch.cuda.device_count():
         raise SystemExit("rank %d: local rank %d but %d device(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     backend = os.environ.get("NTT_BENCH_BACKEND", "nccl")

@@ -298,3 +298,28 @@ def test_phase_stamp_reducer_on_synthetic_records():
     assert [p["ends_at_stamp"] for p in o2["phases"]] == [2, 3, 4, 5, 6, 7, 0]
     assert o2["phases"][0]["cycles_mean"] == pytest.approx(200) and o2["phases"][-1]["cycles_mean"] == pytest.approx(140)
     assert ps.reduce_region(np.zeros((3, 128), dtype=np.uint64), 2, False, 8, 16, 256)["waves_sampled"] == 0
+
+
+def test_power_model_fit_reproduces_its_own_line_and_halves_cycle_savings():
+    """tools/power_model.py: the three-term energy model is fitted to the committed power probe; it must reproduce the transform's
+    own (clock, time), return roughly HALF of a cycle saving as time under the cap (MI355X_MICROARCH.md DVFS give-back; round 5's
+    8-wave bound measured -2.9 % for -4.8 % cycles), and price a single HBM trip above any cycle saving on offer."""
+    import glob
+
+    import power_model as pm
+
+    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_power_probe.txt")))[-1]
+    probe = pm.parse_probe(open(path).read())
+    assert {"idle-ish (sync only)", "forward (real)", "forward (L2 loads, no stores)", "copy (xor kernel)"} <= set(probe)
+    m = pm.fit(probe)
+    f, t = pm.solve(m)
+    assert f == pytest.approx(m["f_real_GHz"], rel=2e-3) and t == pytest.approx(m["t_real_ms"], rel=2e-3)
+    assert 2.0 < m["alpha"] < 4.5 and m["E_mem_J"] > m["shares_at_operating_point"]["butterflies"]  # HBM trips: the largest share
+    _, t10 = pm.solve(m, cycles_scale=0.9)
+    assert 0.35 < (1 - t10 / t) / 0.10 < 0.65  # about half of a cycle saving returns as time
+    _, t1trip = pm.solve(m, mem_scale=0.5)
+    assert t1trip < pm.solve(m, cycles_scale=0.8)[1]
+    # an un-capped case: no energy at all beyond idle -> the clock stays at f_max and time follows cycles
+    free = dict(m, E_mem_J=0.0, E_valu_J_at_f0=0.0)
+    f2, t2 = pm.solve(free, cycles_scale=0.5)
+    assert f2 == 2.4 and t2 == pytest.approx(0.5 * m["cycles"] / 2.4e9 * 1e3)
