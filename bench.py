@@ -723,8 +723,9 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
 # ---- the other single-GPU BASELINE configurations, in the same driver-run line ---------------------------------------------
 # The reference prints every timing it publishes from the one program the user runs (src/test.cpp:157-175).  After the headline's
 # timed region and verification, rank 0 of a one-GPU default run measures BASELINE config 2 (N = 2^12, 32-bit prime, batch 1024,
-# forward) and config 4 (N = 2^20 negacyclic product, Goldilocks, batch 512) for a few steps each and verifies each without the
-# oracle; config 3's inverse leg is the `inverse` key.  tools/configs.py holds the shapes and their algorithmic bytes.
+# forward), config 4 (N = 2^20 negacyclic product, Goldilocks, batch 512) and the per-GPU shard of config 5 (8192 of the 8-GPU job's
+# 65536 rows) for a few steps each and verifies each without the oracle; config 3's inverse leg is the `inverse` key.
+# tools/configs.py holds the shapes and their algorithmic bytes.
 def synth_u32(torch, batch, n, p, device, seed=SEED, first_row=0):
     """[batch][n] residues of a 32-bit modulus as int32 bit patterns: a[b][i] = splitmix64(seed + (first_row + b)*n + i) mod p.
     The unsigned 64-bit word u = hi*2^32 + lo is reduced as ((hi mod p) * (2^32 mod p) + lo) mod p, which fits int64 when
@@ -843,8 +844,10 @@ def run_config(torch, key, stream, src_hash, steps):
     def synth(first_row):
         return synth_batch(torch, batch, n, dev, first_row=first_row) if wb == 8 else synth_u32(torch, batch, n, p, dev, first_row=first_row)
 
-    base_row = {"cfg2": 1 << 20, "cfg2_sat": 1 << 21, "cfg4": 1 << 22}.get(key, 1 << 23)  # rows the headline's batch never uses
-    entry = {"name": c["name"], "key": key, "baseline_config": {"cfg2": 2, "cfg4": 4}.get(key), "logn": logn, "word_bytes": wb,
+    # rows of the job's generator: the headline's batch never uses the first three ranges; config 5's shard is rank 3's rows of the
+    # 8-GPU job ([3 * 8192, 4 * 8192) of its [65536][N] input)
+    base_row = {"cfg2": 1 << 20, "cfg2_sat": 1 << 21, "cfg4": 1 << 22, "cfg5_shard": 3 * 8192}.get(key, 1 << 23)
+    entry = {"name": c["name"], "key": key, "baseline_config": {"cfg2": 2, "cfg4": 4, "cfg5_shard": 5}.get(key), "logn": logn, "word_bytes": wb,
              "modulus": p, "batch": batch, "op": c["op"], "steps": steps, "data": "synthetic (splitmix64 mod p, rows %d.. of the job's generator)" % base_row}
     words = algorithmic_bytes(c) // 2 // wb
     if c["op"] == "forward":
@@ -925,7 +928,7 @@ def extra_configs(torch, stream, src_hash, steps=10):
     """[entry per config] and whether every entry that ran verified; an entry that could not run (exception) is reported with
     its error and counts as NOT verified -- it never stops the headline line from being printed."""
     out = []
-    for key in ("cfg2", "cfg4"):
+    for key in ("cfg2", "cfg4", "cfg5_shard"):
         try:
             with torch.cuda.stream(stream):
                 out.append(run_config(torch, key, stream, src_hash, steps))

@@ -295,13 +295,15 @@ def test_bench_json_contract_frac_step_and_gpu_input_sample():
     assert d["all_ranks_verified"] is True and d["world_size_seen"] == 1 and d["ranks"][0]["rank"] == 0
     assert d["launch"] == "process-per-gpu" and "r02_power_probe" not in r["bound_note"]
     # configs 2 and 4, driver-observed: one entry each, verified, with the roofline keys of the headline
-    assert [e["key"] for e in d["configs"]] == ["cfg2", "cfg4"] and d["configs_all_verified"] is True
-    c2, c4 = d["configs"]
+    assert [e["key"] for e in d["configs"]] == ["cfg2", "cfg4", "cfg5_shard"] and d["configs_all_verified"] is True
+    c2, c4, c5 = d["configs"]
+    assert c5["baseline_config"] == 5 and c5["batch"] == 8192 and c5["verified"] and c5["hbm_passes"] == 2 and c5["unit"] == "NTT/s"
+    assert 0.5 * d["value"] < c5["value"] < 1.5 * d["value"]  # the shard runs at the headline's rate (twice the rows, twice the time)
     assert c2["baseline_config"] == 2 and c2["verified"] and c2["verification"]["round_trip_identical"] and c2["verification"]["coefficient_sum_invariant"]
     assert c2["unit"] == "NTT/s" and 0 < c2["ms"] < 1.0 and abs(c2["value"] - 1024 / (c2["ms"] * 1e-3)) / c2["value"] < 1e-9
     assert c4["baseline_config"] == 4 and c4["verified"] and c4["verification"]["evaluation_at_root_of_xN_plus_1"] and c4["verification"]["transform_domain_identity_whole_batch"]
     assert c4["unit"] == "products/s" and 1.0 < c4["ms"] < 100.0
-    for e in (c2, c4):
+    for e in (c2, c4, c5):
         rr = e["roofline"]
         assert 0 < rr["frac"] <= rr["frac_ceiling"] <= 1.0 and rr["peak"] == 8000.0 and rr["unit"] == "GB/s" and rr["bound"]
         assert abs(rr["achieved"] - rr["algorithmic_bytes_per_op"] / (e["ms"] * 1e-3) / 1e9) / rr["achieved"] < 1e-9

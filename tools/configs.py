@@ -12,6 +12,9 @@ CONFIGS = {
                  op="forward", kind=0),
     "cfg4": dict(name="BASELINE config 4: N=2^20 negacyclic product (NTT -> pointwise -> iNTT), Goldilocks, batch 512", logn=20, p=GOLD,
                  g=7, wb=8, batch=512, op="polymul", kind=2),
+    # config 5 is an 8-GPU job (65536 rows = 8 x 8192, no data-path collective): what ONE GPU of it does is this shard
+    "cfg5_shard": dict(name="BASELINE config 5's per-GPU shard: N=2^16 forward, Goldilocks, 8192 of the job's 65536 rows on one MI355X", logn=16,
+                       p=GOLD, g=7, wb=8, batch=8192, op="forward", kind=0),
 }
 
 

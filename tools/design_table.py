@@ -131,6 +131,10 @@ def configs():
                    hv["instr_per_butterfly_mean"], hv["frac_of_peak_at_held_clock"], " / ".join("%.1f" % w for w in hv["mean_waves_per_simd"]),
                    " / ".join("%.2f" % h for h in hv["held_clock_GHz"]), hr["bound"]))
     out.append(row("4: N = 2^20 negacyclic product, Goldilocks, batch 512, 9 N convention (`%s_bench.json: configs[1]`, `%s_cfg4_*`)" % (R, R), e4["ms"], e4["roofline"], ver(e4)))
+    if "cfg5_shard" in line:
+        e5 = line["cfg5_shard"]
+        out.append(row("5's per-GPU shard: N = 2^16, Goldilocks, 8192 of the 8-GPU job's 65536 rows on ONE GPU (`%s_bench.json: configs[2]`; the 8-rank job itself has "
+                       "never run: no node)" % R, e5["ms"], e5["roofline"], ver(e5)))
     return "\n".join(out) + "\n"
 
 
