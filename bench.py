@@ -133,27 +133,32 @@ def cpu_baseline(logn, p, table, rows_fn, batch, cpu_seconds=20.0, threads=None)
             "value_all_cores": rate_n, "value_1thread": rate_1, "butterflies_per_s": best * (n // 2) * logn}
 
 
-def device_copy_rate(torch, x, y, stream, reps=10):
+def device_copy_rate(torch, x, y, stream, reps=10, rounds=3):
     """The achievable stream rate of this device, in this process, on these buffers: read every byte of x once and
-    write it once to y (the same algorithmic bytes as one transform).  Two forms, best kept: the runtime's
-    device-to-device copy and a plain elementwise kernel."""
+    write it once to y (the same algorithmic bytes as one transform).  Two forms -- the runtime's device-to-device copy and a
+    plain elementwise kernel -- `rounds` timed bursts of `reps` each, the best burst kept: the figure is a capability (what
+    plain streaming CAN reach here), so the fastest observation is the one that bounds the transform's trips."""
     def timed(fn):
-        for _ in range(2):
+        for _ in range(3):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(reps):
-            fn()
-        e1.record(stream)
-        e1.synchronize()
-        return e0.elapsed_time(e1) / reps
+        best = None
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(reps):
+                fn()
+            e1.record(stream)
+            e1.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            best = ms if best is None or ms < best else best
+        return best
 
     nbytes = 2.0 * x.numel() * x.element_size()
     ms_copy = timed(lambda: y.copy_(x))
     ms_elem = timed(lambda: torch.bitwise_xor(x, 1, out=y))
     best = min(ms_copy, ms_elem)
     return {"GBs": nbytes / (best * 1e-3) / 1e9, "ms": best, "ms_memcpy_d2d": ms_copy, "ms_elementwise_kernel": ms_elem,
-            "bytes": nbytes}
+            "bytes": nbytes, "what": "best of %d bursts of %d back-to-back copies, two forms" % (rounds, reps)}
 
 
 def valu_floor(torch, logn, p, batch, x, y, stream, reps=5):
@@ -308,7 +313,7 @@ def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, issue_model=None
                 "what": "the share of the kernels' cycles that the VALU instructions account for when each is priced at the issue "
                         "cost measured at this occupancy; the remainder is LDS exchange, waits on memory and barriers",
             }
-        out["saturated"] = bool(out["frac_of_peak_at_held_clock"] >= 0.9)
+        out["saturated"] = bool(out["frac_of_peak_at_held_clock"] >= SATURATED)
         wv = "/".join("%.1f" % w for w in waves) if all(w for w in waves) else "~4"
         st = "/".join("%.2f" % x for x in stall) if all(x is not None for x in stall) else "n/a"
         out["verdict"] = ("vector-ALU at %.0f %% of its SIMD-32 peak at the held clock: saturated, an instruction saved returns as time"
@@ -320,10 +325,15 @@ def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, issue_model=None
     return out
 
 
+# A roofline is NAMED as the bound only at this fraction of it.  The headline's passes stream at 0.87-0.93 of a same-run device copy
+# from box to box (the copy's own rate moves 3 % between runs): a 0.9 threshold made the label flip between two runs of one build.
+SATURATED = 0.95
+
+
 def decide_bound(pass_frac_of_copy, valu_frac_of_peak, waves=None, held_clock_GHz=None):
     """roofline.bound from the run's own numbers, never asserted:
-      "hbm"        every pass streams at >= 0.9 of the same-run device copy
-      "valu"       the vector ALU is at >= 0.9 of its SIMD-32 peak at the held clock
+      "hbm"        every pass streams at >= SATURATED (0.95) of the same-run device copy
+      "valu"       the vector ALU is at >= 0.95 of its SIMD-32 peak at the held clock
       "power-cap"  neither, and the kernels hold less than 0.9 of the 2.4 GHz peak clock: the board power cap (1400 W) is the
                    resource that is exhausted -- HBM traffic and VALU work both cost joules, and the clock is what gives
                    (profiles/rNN_power_probe.txt: the transform draws 1359-1397 W at 1.91-1.94 GHz, its VALU work alone 1132 W at
@@ -332,9 +342,9 @@ def decide_bound(pass_frac_of_copy, valu_frac_of_peak, waves=None, held_clock_GH
       "unsaturated" none of the above can be shown (no counters for these sources, or the clock is held): nothing is claimed
     Returns (bound, detail).  Pure arithmetic (CPU unit test)."""
     hb = min(pass_frac_of_copy) if pass_frac_of_copy else None
-    if hb is not None and hb >= 0.9:
+    if hb is not None and hb >= SATURATED:
         return "hbm", "every pass streams at >= %.2f of the same-run device copy" % hb
-    if valu_frac_of_peak is not None and valu_frac_of_peak >= 0.9:
+    if valu_frac_of_peak is not None and valu_frac_of_peak >= SATURATED:
         return "valu", "vector ALU at %.2f of its SIMD-32 peak at the held clock" % valu_frac_of_peak
     w = ("%.1f" % (sum(waves) / len(waves))) if waves and all(waves) else "~4"
     what = "passes stream at %s of the device copy, vector ALU at %s of its SIMD-32 peak (%s waves per SIMD)" % (
@@ -645,7 +655,7 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
     out["roofline"] = {
         # The contract's figure: algorithmic HBM bytes / kernel time against the 8 TB/s spec peak (achieved, peak, unit, frac);
         # `roofline_of_fields` says which roofline those four numbers are.  `bound` is decided from the run's numbers
-        # (decide_bound): "hbm" / "valu" only when that unit is at >= 0.9 of what it can do; "power-cap" when neither is and the
+        # (decide_bound): "hbm" / "valu" only when that unit is at >= 0.95 of what it can do; "power-cap" when neither is and the
         # kernels hold less than 0.9 of the peak clock; "unsaturated" when nothing can be shown.
         "bound": bound, "bound_detail": bound_detail, "roofline_of_fields": "hbm",
         "bound_note": "achieved/peak/frac are the HBM roofline SURVEY 8(d) prescribes (algorithmic bytes over the spec peak); "
@@ -792,6 +802,28 @@ def config_roofline(cfg_key, c, op_ms, copy_ms, passes, src_hash):
     sq, sq_src = tagged_profile("%s_sq_counters" % cfg_key, src_hash)
     traffic = pmc["per_op"]["hbm_bytes"] if pmc else None
     valu = None
+    if cfg_key == "cfg5_shard" and (pmc is None or sq is None):
+        # config 5's shard runs the headline's two kernels at twice the batch: quote THEIR counters (fractions are batch-free; bytes
+        # per launch scale with the rows), and say so
+        hp, hp_src = tagged_profile("pmc_traffic", src_hash)
+        hs, hs_src = tagged_profile("sq_counters", src_hash)
+        shape = [("contig", 0, 8), ("col", 8, 8)]
+        if pmc is None and hp:
+            ent, _ = forward_counters(hp, shape)
+            if ent:
+                traffic = sum(e[1]["hbm_bytes_per_launch"] for e in ent) * c["batch"] / float(hp.get("batch", 4096))
+                pmc_src = hp_src + " -- the headline's launches of the same two kernels, scaled by the rows"
+        if sq is None and hs:
+            ent, _ = forward_counters(hs, shape)
+            if ent and all(e[1].get("kernel_cycles") for e in ent):
+                ins = sum(e[1]["SQ_INSTS_VALU"] for e in ent)
+                cyc = sum(e[1]["kernel_cycles"] for e in ent)
+                valu = {"instr_per_butterfly": ins / (hs["batch"] * (1 << (hs["logn"] - 1)) * hs["logn"] / 64.0),
+                        "frac_of_peak_at_held_clock": valu_frac_of_peak(ins, cyc),
+                        "mean_waves_per_simd": [e[1].get("mean_waves_per_simd") for e in ent],
+                        "held_clock_GHz": [e[1].get("held_clock_GHz") for e in ent], "kernels": [e[1]["short"] for e in ent],
+                        "what": "the headline's counters: the same two pass kernels at batch %d (fractions do not depend on the batch)" % hs["batch"]}
+                sq_src = hs_src + " -- the headline's launches of the same two kernels"
     if sq and sq["per_op"].get("kernel_cycles"):
         po = sq["per_op"]
         valu = {"instr_per_butterfly": po["valu_instr_per_butterfly"],
@@ -905,7 +937,7 @@ def run_config(torch, key, stream, src_hash, steps):
     op_ms = min(med, b2b)
     src = torch.empty(words, dtype=torch.int64 if wb == 8 else torch.int32, device=dev)
     dst = torch.empty_like(src)
-    _, copy_ms = events_ms(torch, lambda: dst.copy_(src), stream, 10, 3)
+    copy_ms = device_copy_rate(torch, src, dst, stream)["ms"]  # a copy of the operation's algorithmic bytes, best of both forms
     del src, dst
     unit = "products/s" if c["op"] == "polymul" else "NTT/s"
     entry.update({"ms": op_ms, "ms_median_single": med, "ms_back_to_back": b2b, "value": batch / (op_ms * 1e-3), "unit": unit,

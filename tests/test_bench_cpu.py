@@ -144,7 +144,7 @@ def test_valu_roofline_arithmetic_on_a_synthetic_mix():
     assert ic["frac_of_kernel_cycles"] > w["frac_of_peak_at_held_clock"]  # dearer per instruction than the peak price
     assert w["frac_of_peak_at_held_clock"] == v["frac_of_peak_at_held_clock"]  # ... which it never replaces
     # a kernel that really sat at the peak would say so
-    fast = [(k, dict(e, kernel_cycles=e["valu_instr_per_butterfly"] * 2 / 0.95 * bf_waves / 1024)) for k, e in ent]
+    fast = [(k, dict(e, kernel_cycles=e["valu_instr_per_butterfly"] * 2 / 0.97 * bf_waves / 1024)) for k, e in ent]
     assert bench.valu_roofline(fast, passes, [0.4, 0.4], 4096, 16)["saturated"] is True
 
 
@@ -153,15 +153,17 @@ def test_decide_bound_from_the_runs_numbers():
     saturated and the kernels hold < 0.9 of the peak clock; "unsaturated" when nothing can be shown."""
     import bench
 
-    assert bench.decide_bound([0.95, 0.93], 0.46)[0] == "hbm"
-    assert bench.decide_bound([0.88, 0.89], 0.93)[0] == "valu"
+    assert bench.SATURATED == 0.95
+    assert bench.decide_bound([0.97, 0.96], 0.46)[0] == "hbm"
+    assert bench.decide_bound([0.88, 0.89], 0.96)[0] == "valu"
+    assert bench.decide_bound([0.93, 0.91], 0.46, [3.7, 3.7], [1.98, 2.02])[0] == "power-cap"  # 0.9-0.95 of a copy is not "hbm": the label must not flip with the copy's own noise
     b, why = bench.decide_bound([0.88, 0.89], 0.46, [3.7, 3.7], [1.95, 1.97])
     assert b == "power-cap" and "0.88" in why and "0.46" in why and "3.7 waves" in why and "1.95" in why
     b, why = bench.decide_bound([0.88, 0.89], 0.46, [3.7, 3.7], [2.38, 2.39])  # the clock is held: no cap to blame
     assert b == "unsaturated"
     b, why = bench.decide_bound([0.88, 0.89], None)
     assert b == "unsaturated" and "n/a" in why  # no counters for these sources: nothing is claimed
-    assert bench.decide_bound(None, 0.95)[0] == "valu"
+    assert bench.decide_bound(None, 0.96)[0] == "valu"
 
 
 def test_synthetic_generators_and_config_checks(oracle):
