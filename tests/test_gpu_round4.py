@@ -245,6 +245,19 @@ def test_bench_every_rank_verifies_and_names_its_device():
     assert max(r["ms_per_step"] for r in d["ranks"]) <= d["ms_per_step"] * 1.001  # the line's time is the max over ranks
 
 
+def test_bench_four_ranks_rehearsal_file_rendezvous():
+    """`bench.py --gpus 4` starting its own four ranks over a FILE rendezvous (round 5: no port is probed; rehearsal: all on cuda:0
+    over gloo, within the box's limit of 6 GPU processes): four shards of the job's rows, four identity records gathered in rank
+    order, the aggregate over all four, and the waived distinctness rule said in the line."""
+    out, d = _bench(["--gpus", "4", "--steps", "2", "--warmup", "1", "--batch", "64"], REHEARSAL)
+    assert out.returncode == 0 and d is not None, out.stdout[-1000:] + out.stderr[-3000:]
+    assert d["n_gpus"] == 4 and d["world_size_seen"] == 4 and [r["rank"] for r in d["ranks"]] == [0, 1, 2, 3]
+    assert d["all_ranks_verified"] is True and d["distinct_devices"] == 1
+    assert d["verification"]["distinctness_waived_one_device_rehearsal"] is True and d["verification"]["ranks_on_distinct_devices"] is None
+    assert abs(d["value"] - 4 * 64 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    assert "configs" not in d and "cpu_baseline" not in d  # N = 1 only
+
+
 def test_bench_one_failing_rank_fails_the_job():
     """A rank whose check fails (test hook NTT_BENCH_INJECT_FAILURE=<rank>: that rank reports round_trip false) turns rank 0's
     line red and the launcher's exit code non-zero -- a timed but wrong rank can no longer hide behind rank 0."""
