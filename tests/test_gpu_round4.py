@@ -278,6 +278,12 @@ def test_bench_single_process_n_devices():
     assert d["value_by_device_events"] >= d["value"] * 0.999  # the wall clock contains the slowest device's events
     assert "hipMemcpyPeer" in d["config"]["table_broadcast"] and "cpu_baseline" not in d
     assert all(r["round_trip_identical"] and r["coefficient_sum_invariant"] for r in d["ranks"])
+    # the node's shape, eight plan clones / streams / shards in one process (rehearsal: all on device 0): config 5's partition
+    out, d = _bench(["--gpus", "8", "--single-process", "--steps", "2", "--warmup", "1", "--batch", "128", "--no-cpu-baseline",
+                     "--no-valu-floor", "--no-inverse"], {"NTT_BENCH_ONE_DEVICE": "1"})
+    assert out.returncode == 0 and d is not None, out.stdout[-1000:] + out.stderr[-3000:]
+    assert d["n_gpus"] == 8 and len(d["ranks"]) == 8 and d["all_ranks_verified"] is True and [r["rank"] for r in d["ranks"]] == list(range(8))
+    assert abs(d["value"] - 8 * 128 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
     # more devices than the box has, no rehearsal switch: refused before any work
     out, d = _bench(["--gpus", "64", "--single-process", "--steps", "1", "--warmup", "0"])
     assert out.returncode == 2 and d is None and "only" in out.stderr

@@ -6,6 +6,7 @@ cycle table.  The reference's analogue: the per-event hardware trace of one tile
 (src/aie_core.cc:129-131, profile/trace/trace_16core_n11.json -- 63 % LockStall).
 
 usage (GPU box): python3 tools/phase_stamps.py [--logn 16] [--batch 4096] [--reps 10] > profiles/rNN_phase_stamps.json
+                 python3 tools/phase_stamps.py --logn 12 --p 3221225473 --g 5 --word-bytes 4 --batch 1024 --shape 4,0,8,512 > profiles/rNN_phase_stamps_cfg2.json
 
 What is measured: the forward transform at the headline shape, `reps` back-to-back launches with stamps on (the last launch's
 records are read).  A stamp waits for the wave's outstanding LDS traffic (and, in kernels that load straight into registers,
@@ -65,6 +66,12 @@ def reduce_region(recs, R, dma, log_m, e_words, nt):
     out["clock_GHz_median"] = float(np.median(life / np.maximum(1.0, real) * 0.1))
     out["iterations_per_wave"] = {"min": int(iters.min()), "median": float(np.median(iters)), "max": int(iters.max())}
     out["wave_lifetime_cycles_median"] = float(np.median(life))
+    # the launch on the 100 MHz wall clock (s_memrealtime, one counter for the whole chip): when the waves START (the dispatcher's
+    # ramp) against how long one of them lives -- a one-generation launch is the sum of the two, not a throughput
+    start, end = live[:, 0].astype(np.float64), live[:, REC - 1].astype(np.float64)
+    out["wall_clock_us"] = {"first_wave_start_to_last_wave_end": float(end.max() - start.min()) / 100.0,
+                            "wave_starts_span_p01_p99": float(np.percentile(start, 99) - np.percentile(start, 1)) / 100.0,
+                            "wave_lifetime_median": float(np.median(end - start)) / 100.0}
     # kernel entry -> the first iteration's first stamp: index set-up + the resident twiddle loads
     out["init_cycles_median"] = float(np.median(live[:, HDR].astype(np.float64) - live[:, 1].astype(np.float64)))
     nst = 2 * R + 4
@@ -115,18 +122,27 @@ def reduce_region(recs, R, dma, log_m, e_words, nt):
 def main():
     import torch
 
-    from bench import GOLDILOCKS, synth_batch
+    from bench import GOLDILOCKS, synth_batch, synth_u32
     from ntt_aie_amd import _lib
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--logn", type=int, default=16)
     ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--p", type=int, default=GOLDILOCKS)
+    ap.add_argument("--g", type=int, default=7)
+    ap.add_argument("--word-bytes", type=int, default=8)
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--shape", action="append", default=None,
+                    help="per pass, in order: R,dma,E,NT (register rounds, 1 if the kernel has an LDS-DMA tile, words per thread, threads per "
+                         "workgroup).  Default = the headline's two kernels: 3,1,8,256 and 2,0,16,256.  BASELINE config 2 (--logn 12 --p "
+                         "3221225473 --g 5 --word-bytes 4 --batch 1024): --shape 4,0,8,512")
     ap.add_argument("--lib", default=os.path.join(ROOT, "ab", "libntt_stamps.so"))
     args = ap.parse_args()
+    shapes = [tuple(int(v) for v in sh.split(",")) for sh in (args.shape or ["3,1,8,256", "2,0,16,256"])]
     torch.cuda.set_device(0)
     n = 1 << args.logn
-    x = synth_batch(torch, args.batch, n, torch.device("cuda", 0))
+    dev = torch.device("cuda", 0)
+    x = synth_batch(torch, args.batch, n, dev) if args.word_bytes == 8 else synth_u32(torch, args.batch, n, args.p, dev)
     y, yref = torch.empty_like(x), torch.empty_like(x)
     stream = torch.cuda.current_stream()
     LS = _lib.open_library(args.lib)
@@ -135,12 +151,14 @@ def main():
     plans = {}
     for name, L in (("stamps", LS), ("product", LP)):
         h = C.c_void_p()
-        assert L.ntt_plan_create(C.byref(h), args.logn, GOLDILOCKS, 8, 0) == 0
-        assert L.ntt_plan_generate_twiddles(h, 0, 7) == 0
+        assert L.ntt_plan_create(C.byref(h), args.logn, args.p, args.word_bytes, 0) == 0
+        assert L.ntt_plan_generate_twiddles(h, 0, args.g) == 0
         plans[name] = (L, h)
-    npass = int(LS.ntt_plan_info(plans["stamps"][1], 3))
-    assert npass == 2, "phase_stamps.py stamps two-pass transforms (one record region per pass kind)"
-    stages = [int(LS.ntt_plan_info(plans["stamps"][1], 32 + i)) for i in range(npass)]
+    # the decomposition the launcher runs for THIS batch (plan alternatives): one record region per pass kind (CONTIG, column)
+    alt = int(LS.ntt_plan_select(plans["stamps"][1], args.batch))
+    npass = int(LS.ntt_plan_info(plans["stamps"][1], 256 + 16 * alt))
+    assert npass in (1, 2) and npass == len(shapes), "one --shape per pass; at most one CONTIG and one column pass (one record region each)"
+    stages = [int(LS.ntt_plan_info(plans["stamps"][1], 256 + 16 * alt + 1 + i)) for i in range(npass)]
     records = 1 << 18  # two regions of 2^17 wave records (a launch of the headline has 8192 x 4 / 16384 x 4 waves)
     buf = torch.zeros((records, REC), dtype=torch.int64, device="cuda:0")
     ms, k = (C.c_float * 8)(), C.c_int(0)
@@ -175,13 +193,16 @@ def main():
     def med(rows, i):
         return statistics.median(r[i] for r in rows)
 
+    regions = [recs[:half], recs[half:]]
     out = {"src_hash": _lib.kernel_source_hash(), "device": torch.cuda.get_device_name(0), "logn": args.logn, "batch": args.batch,
+           "modulus": args.p, "word_bytes": args.word_bytes,
            "library": os.path.relpath(args.lib, ROOT), "outputs_identical_to_product_library": same,
            "method": __doc__.split("usage")[0].strip(),
            "overhead": {"product_pass_ms": [med(tp, i) for i in range(npass)], "stamped_pass_ms": [med(ts, i) for i in range(npass)],
                         "stamped_over_product": [med(ts, i) / med(tp, i) for i in range(npass)]},
-           "passes": [dict(kind="contig (LDS-DMA, radix-8 rounds 3+3+2)", **reduce_region(recs[:half], 3, True, stages[0], 8, 256)),
-                      dict(kind="column (radix-16 rounds 4+4)", **reduce_region(recs[half:], 2, False, stages[1], 16, 256))]}
+           "passes": [dict(kind="%s pass, %d stages: %d register rounds of radix %d%s, %d threads per workgroup" % (
+                               "CONTIG" if i == 0 else "column", stages[i], sh[0], sh[2], ", LDS-DMA tile" if sh[1] else "", sh[3]),
+                           **reduce_region(regions[i], sh[0], bool(sh[1]), stages[i], sh[2], sh[3])) for i, sh in enumerate(shapes)]}
     json.dump(out, sys.stdout, indent=1)
     print()
     if not same:
