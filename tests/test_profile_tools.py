@@ -323,3 +323,38 @@ def test_power_model_fit_reproduces_its_own_line_and_halves_cycle_savings():
     free = dict(m, E_mem_J=0.0, E_valu_J_at_f0=0.0)
     f2, t2 = pm.solve(free, cycles_scale=0.5)
     assert f2 == 2.4 and t2 == pytest.approx(0.5 * m["cycles"] / 2.4e9 * 1e3)
+
+
+def test_phase_stamp_chrome_trace_is_in_the_references_trace_format():
+    """tools/phase_stamps.py --trace-prefix: one CU's waves as chrome-trace events with the keys of the reference's
+    profile/trace/*.json (name, ts in cycles, ph B / E / M, pid, tid): B and E balance per row, time never runs backwards within
+    a row, only the first recorded wave's CU is traced."""
+    import numpy as np
+
+    import phase_stamps as ps
+
+    recs = np.zeros((6, 128), dtype=np.uint64)
+    for w in range(4):
+        r = recs[w]
+        r[0], r[1], r[3] = 1000, 5000 + 10 * w, 2
+        r[2] = (3 << 32) | (0x21 << 8) | ((w % 4) << 4) | (w // 4)  # XCC 3, CU byte 0x21, SIMD w, wave 0
+        t = 6000 + 10 * w
+        for it in range(2):
+            for k in range(10):
+                r[4 + it * 12 + k] = t
+                t += 100
+            t += 50
+        r[126], r[127] = t, 1100
+    recs[4, 1], recs[4, 2] = 7000, (5 << 32) | (0x33 << 8)  # a wave of ANOTHER CU: not traced
+    ev = ps.chrome_trace(recs, 3, True)
+    meta = [e for e in ev if e["ph"] == "M"]
+    assert meta[0]["name"] == "process_name" and "XCC 3" in meta[0]["args"]["name"] and len(meta) == 1 + 4
+    assert {e["args"]["name"] for e in meta[1:]} == {"SIMD %d wave 0" % k for k in range(4)}
+    body = [e for e in ev if e["ph"] != "M"]
+    assert all(set(e) == {"name", "ts", "ph", "pid", "tid", "args"} for e in body)
+    for tid in range(4):
+        row = [e for e in body if e["tid"] == tid]
+        assert [e["ph"] for e in row] == ["B", "E"] * (len(row) // 2) and all(a["ts"] <= b["ts"] for a, b in zip(row, row[1:]))
+        assert len(row) == 2 * (1 + 2 * 9)  # init + 9 phases x 2 iterations
+        assert row[0]["name"].startswith("init") and row[2]["name"] == "wait" and any(e["name"].startswith("round 0") for e in row)
+    assert ps.chrome_trace(np.zeros((2, 128), dtype=np.uint64), 3, True) == []

@@ -119,6 +119,47 @@ def reduce_region(recs, R, dma, log_m, e_words, nt):
     return out
 
 
+def chrome_trace(recs, R, dma, window_cycles=300000, label="pass"):
+    """Chrome-trace events (the format of the reference's profile/trace/*.json: name / ts / ph B|E / pid / tid, ts in CYCLES) for the
+    waves of ONE compute unit -- the analogue of the reference's one traced tile (src/aie2.py:157-158, tile (0,0)).  The CU is the one
+    the first recorded wave ran on (HW_ID: cu, sh, se + XCC id); rows are its wave slots (SIMD, wave id), events the phases between
+    two stamps, the first `window_cycles` cycles of the launch on that CU.  Pure numpy (CPU unit test)."""
+    recs = np.asarray(recs, dtype=np.uint64)
+    live = recs[recs[:, 1] != 0]
+    if not len(live):
+        return []
+    hw = live[:, 2]
+    cu_key = ((hw >> np.uint64(8)) & np.uint64(0xFF)) | ((hw >> np.uint64(32)) << np.uint64(8))  # CU_ID | SH_ID | SE_ID, XCC above
+    mine = live[cu_key == cu_key[0]]
+    t0 = float(mine[:, 1].min())
+    names = phase_names(R, dma)
+    nst = 2 * R + 4
+    slots = sorted(set(int(h & np.uint64(0x3F)) for h in mine[:, 2]))  # SIMD_ID [5:4] | WAVE_ID [3:0]
+    ev = [{"name": "process_name", "ph": "M", "pid": 0, "args": {"name": "%s: phase stamps of one CU (XCC %d, HW_ID[15:8] 0x%02x)" % (
+        label, int(mine[0, 2] >> np.uint64(32)) & 15, int(mine[0, 2] >> np.uint64(8)) & 0xFF)}}]
+    for i, sl in enumerate(slots):
+        ev.append({"name": "thread_name", "ph": "M", "pid": 0, "tid": i, "args": {"name": "SIMD %d wave %d" % (sl >> 4, sl & 15)}})
+    tid_of = {sl: i for i, sl in enumerate(slots)}
+    for row in mine[np.argsort(mine[:, 1])]:
+        tid = tid_of[int(row[2] & np.uint64(0x3F))]
+        start = float(row[1]) - t0
+        if start > window_cycles:
+            continue
+        t = row[HDR:HDR + 8 * PER_IT].astype(np.float64).reshape(8, PER_IT) - t0
+        ev.append({"name": "init (indices, resident twiddles)", "ts": start, "ph": "B", "pid": 0, "tid": tid, "args": {}})
+        ev.append({"name": "init (indices, resident twiddles)", "ts": float(t[0, 0]), "ph": "E", "pid": 0, "tid": tid, "args": {}})
+        for it in range(min(int(row[3]), 8)):
+            prev = 0
+            for k in range(1, nst):
+                if not dma and k == 1:
+                    continue
+                nm = names[k].split(" (")[0].split(":")[0]
+                ev.append({"name": nm, "ts": float(t[it, prev]), "ph": "B", "pid": 0, "tid": tid, "args": {"iteration": it}})
+                ev.append({"name": nm, "ts": float(t[it, k]), "ph": "E", "pid": 0, "tid": tid, "args": {}})
+                prev = k
+    return ev
+
+
 def main():
     import torch
 
@@ -137,6 +178,10 @@ def main():
                          "workgroup).  Default = the headline's two kernels: 3,1,8,256 and 2,0,16,256.  BASELINE config 2 (--logn 12 --p "
                          "3221225473 --g 5 --word-bytes 4 --batch 1024): --shape 4,0,8,512")
     ap.add_argument("--lib", default=os.path.join(ROOT, "ab", "libntt_stamps.so"))
+    ap.add_argument("--trace-prefix", default=None,
+                    help="also write <prefix>_<pass>.json: chrome-trace events (the reference's profile/trace format) of ONE compute unit's waves, "
+                         "the first --trace-cycles cycles of the launch")
+    ap.add_argument("--trace-cycles", type=int, default=300000)
     args = ap.parse_args()
     shapes = [tuple(int(v) for v in sh.split(",")) for sh in (args.shape or ["3,1,8,256", "2,0,16,256"])]
     torch.cuda.set_device(0)
@@ -203,6 +248,14 @@ def main():
            "passes": [dict(kind="%s pass, %d stages: %d register rounds of radix %d%s, %d threads per workgroup" % (
                                "CONTIG" if i == 0 else "column", stages[i], sh[0], sh[2], ", LDS-DMA tile" if sh[1] else "", sh[3]),
                            **reduce_region(regions[i], sh[0], bool(sh[1]), stages[i], sh[2], sh[3])) for i, sh in enumerate(shapes)]}
+    if args.trace_prefix:
+        for i, sh in enumerate(shapes):
+            name = "contig" if i == 0 else "column"
+            ev = chrome_trace(regions[i], sh[0], bool(sh[1]), args.trace_cycles, "%s pass, N=2^%d batch %d" % (name, args.logn, args.batch))
+            with open("%s_%s.json" % (args.trace_prefix, name), "w") as f:
+                json.dump(ev, f)
+            out["passes"][i]["trace_file"] = os.path.basename("%s_%s.json" % (args.trace_prefix, name))
+            out["passes"][i]["trace_events"] = len(ev)
     json.dump(out, sys.stdout, indent=1)
     print()
     if not same:
