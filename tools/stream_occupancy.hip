@@ -15,14 +15,17 @@
 
 #include "gl_asm_w.h"
 
-constexpr int ITERS = 1500;
+constexpr int ITERS = 1600;  // radix-8 rounds per wave (a multiple of every UNROLL)
 constexpr int CUS = 256;
 
 struct Stamp {
     unsigned long long cycles, ticks;
 };
 
-template <int MODE>  // 0: the stream as shipped (22 VALU + 5 SALU per butterfly); 1: two rounds' worth of independent data per iteration (16 words: more statements in flight per wave is NOT possible with one scratch set -- kept for symmetry: same as 0 on words 8..15)
+// UNROLL: how many radix-8 rounds one loop iteration holds as straight-line code (1: 6 statements, 2.7 KB -- every wave of the CU runs
+// the same few cache lines; 8: 48 statements, ~21 KB -- the footprint of a pass kernel's batch loop, and waves drift apart in it).
+// Same work per launch either way: does the statement slow down when the instruction stream is long?
+template <int UNROLL>
 __global__ void __launch_bounds__(256, 8) k_round8(uint32_t *out, Stamp *st, int iters, uint32_t seed) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using namespace ntt;
@@ -37,7 +40,10 @@ __global__ void __launch_bounds__(256, 8) k_round8(uint32_t *out, Stamp *st, int
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_sched_barrier(0);
-    for (int it = 0; it < iters; ++it) {
+    // waves of a workgroup start at different places of the long body (they would drift apart anyway in a real kernel)
+    for (int it = (UNROLL > 1 ? (int) (threadIdx.x >> 6) : 0); it < iters / UNROLL; ++it) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++)
 #pragma unroll
         for (int s = 0; s < 3; s++) {
             const int h = 1 << s;
@@ -70,36 +76,42 @@ int main() {
     hipMalloc(&d_out, max_threads * sizeof(uint32_t));
     hipMalloc(&d_st, max_threads / 64 * sizeof(Stamp));
     std::vector<Stamp> h(max_threads / 64);
-    auto kern = k_round8<0>;
-    hipFuncAttributes fa;
-    hipFuncGetAttributes(&fa, (const void *) kern);
-    printf("# gl_fwd2_v_w as a register-resident radix-8 round (12 butterflies per iteration, %d iterations); kernel: %d VGPRs, %d SGPRs\n", ITERS, fa.numRegs, 0);
-    printf("# waves/SIMD  cycles per butterfly per SIMD  cycles per VALU instruction (22)  clock GHz\n");
-    for (int w = 1; w <= 8; w++) {
-        const int blocks = CUS * w;
-        const size_t lds = (160 * 1024 / w) - 512;
-        if (hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) return 1;
-        for (int k = 0; k < 2; k++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_out, d_st, ITERS, 12345u + k);
-        hipDeviceSynchronize();
-        std::vector<double> cyc, ghz;
-        for (int r = 0; r < 5; r++) {
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_out, d_st, ITERS, 777u + r);
+    struct V { const char *name; void (*k)(uint32_t *, Stamp *, int, uint32_t); int unroll; };
+    const V variants[] = {{"loop body = 1 round (2.7 KB)", k_round8<1>, 1}, {"loop body = 4 rounds (~11 KB)", k_round8<4>, 4}, {"loop body = 8 rounds (~21 KB)", k_round8<8>, 8}};
+    for (const V &v : variants) {
+        auto kern = v.k;
+        hipFuncAttributes fa;
+        hipFuncGetAttributes(&fa, (const void *) kern);
+        printf("# gl_fwd2_v_w as register-resident radix-8 rounds (12 butterflies each, %d per wave), %s; kernel: %d VGPRs\n", ITERS, v.name, fa.numRegs);
+        printf("# waves/SIMD  cycles per butterfly per SIMD  cycles per VALU instruction (22)  clock GHz\n");
+        for (int w = 1; w <= 8; w++) {
+            const int blocks = CUS * w;
+            const size_t lds = (160 * 1024 / w) - 512;
+            if (hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) return 1;
+            for (int k = 0; k < 2; k++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_out, d_st, ITERS, 12345u + k);
             hipDeviceSynchronize();
-            const size_t nw = (size_t) blocks * 4;
-            hipMemcpy(h.data(), d_st, nw * sizeof(Stamp), hipMemcpyDeviceToHost);
-            std::vector<unsigned long long> c(nw), t(nw);
-            for (size_t i = 0; i < nw; i++) c[i] = h[i].cycles, t[i] = h[i].ticks;
-            std::nth_element(c.begin(), c.begin() + nw / 2, c.end());
-            std::nth_element(t.begin(), t.begin() + nw / 2, t.end());
-            cyc.push_back((double) c[nw / 2]);
-            ghz.push_back((double) c[nw / 2] / ((double) t[nw / 2] * 10.0));
+            std::vector<double> cyc, ghz;
+            for (int r = 0; r < 5; r++) {
+                hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_out, d_st, ITERS, 777u + r);
+                hipDeviceSynchronize();
+                const size_t nw = (size_t) blocks * 4;
+                hipMemcpy(h.data(), d_st, nw * sizeof(Stamp), hipMemcpyDeviceToHost);
+                std::vector<unsigned long long> c(nw), t(nw);
+                for (size_t i = 0; i < nw; i++) c[i] = h[i].cycles, t[i] = h[i].ticks;
+                std::nth_element(c.begin(), c.begin() + nw / 2, c.end());
+                std::nth_element(t.begin(), t.begin() + nw / 2, t.end());
+                cyc.push_back((double) c[nw / 2]);
+                ghz.push_back((double) c[nw / 2] / ((double) t[nw / 2] * 10.0));
+            }
+            if (hipGetLastError() != hipSuccess) return 2;
+            std::sort(cyc.begin(), cyc.end());
+            std::sort(ghz.begin(), ghz.end());
+            // wave w of a workgroup skips its first w iterations of the long body: median wave (1.5 skipped) ~ the nominal count
+            const double rounds = (v.unroll > 1) ? (double) (ITERS / v.unroll - 1.5) * v.unroll : (double) ITERS;
+            const double per_bf = cyc[2] / (w * 12.0 * rounds);
+            printf("%d  %.2f  %.3f  %.3f\n", w, per_bf, per_bf / 22.0, ghz[2]);
+            fflush(stdout);
         }
-        if (hipGetLastError() != hipSuccess) return 2;
-        std::sort(cyc.begin(), cyc.end());
-        std::sort(ghz.begin(), ghz.end());
-        const double per_bf = cyc[2] / (w * 12.0 * ITERS);
-        printf("%d  %.2f  %.3f  %.3f\n", w, per_bf, per_bf / 22.0, ghz[2]);
-        fflush(stdout);
     }
     return 0;
 }
