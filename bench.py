@@ -37,7 +37,8 @@ sys.path.insert(0, ROOT)
 
 GOLDILOCKS = 0xFFFFFFFF00000001
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from hw import HBM_PEAK_GBS, PEAK_CLOCK_GHZ, SIMDS, VALU_PEAK_CYCLES_PER_WAVE_INSTR  # noqa: E402  (tools/hw.py: the one place the peaks live)
+from hw import (HBM_PEAK_GBS, PEAK_CLOCK_GHZ, SIMDS, VALU_PEAK_CYCLES_PLAIN, VALU_PEAK_CYCLES_VOP3, VALU_PEAK_SOURCE,  # noqa: E402
+                valu_frac_of_peak, valu_peak_cycles)  # tools/hw.py: the one place the peaks live
 
 SEED = 0x9E3779B97F4A7C15  # a[b][i] = splitmix64(SEED + b*N + i) mod p
 PROFILE_ROUND = "r05"  # the collection DESIGN.md section 4 is generated from (tools/design_table.py); counters are quoted from the newest matching round (tagged_profile)
@@ -239,28 +240,46 @@ def forward_counters(summary, passes, field="FieldGL"):
     return out, None
 
 
-def weighted_issue_cycles(stream_mix, instr_per_butterfly, costs, overhead_cycles=VALU_PEAK_CYCLES_PER_WAVE_INSTR,
-                          default_cycles=VALU_PEAK_CYCLES_PER_WAVE_INSTR):
-    """Issue cycles per wave-butterfly of one pass kernel: the butterfly stream's instructions priced by class with MEASURED
-    cycles per wave-instruction (profiles/rNN_valu_issue_cost.json), plus the instructions the counter sees beyond the stream
-    (SQ_INSTS_VALU per butterfly - stream length: addressing, register moves) at `overhead_cycles` each.
-    stream_mix = {"valu": n, "mix": {class: count}}; costs = {class: cycles}.  Pure arithmetic (CPU unit test)."""
-    stream = sum(n * costs.get(c, default_cycles) for c, n in stream_mix["mix"].items())
-    extra = max(0.0, instr_per_butterfly - stream_mix["valu"])
-    return stream + extra * overhead_cycles
+def stream_plain_counts(passes):
+    """(VALU instructions, of which plain moves / adds) of ONE forward Goldilocks butterfly statement per pass, from the generator's
+    own instruction lists (tools/valu_mix.py -> tools/gen_gl_asm.py: no GPU, no file): the first pass reads its twiddles from VGPRs,
+    column passes from SGPRs -- same counts, 22 VALU of which 2 moves."""
+    from valu_mix import stream_mix
+
+    out = []
+    for kind, _, _ in passes:
+        m = stream_mix("fwd", kind != "contig")
+        out.append((m["valu"], m["mix"].get("plain", 0)))
+    return out
 
 
-def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, issue_model=None):
-    """The vector-ALU roofline of the forward transform, on the SIMD-32 peak (tools/hw.py; MI355X_MICROARCH.md: a wave64 VALU
-    instruction takes 2 cycles of a SIMD's throughput).
-      peak butterflies/s = SIMDs x clock / (2 cycles x VALU instructions per butterfly) x 64 lanes
-      frac_of_peak_at_held_clock = instructions x 2 cycles x wave-butterflies / (SIMDs x the launch's shader cycles): clock-free
-    issue_model = {"costs": {class: cycles at the kernels' occupancy}, "streams": [stream mix per pass], ...} adds a SECOND figure,
-    named for what it is: `issue_cost_at_kernel_occupancy` -- what the same instructions cost when only ~4 waves share a SIMD
-    (profiles/rNN_valu_issue_cost.json).  That is a property of the kernels' occupancy, not the unit's capacity, and is never
-    called a peak."""
+def statement_steady_state():
+    """{waves per SIMD: cycles per butterfly per SIMD} of the forward butterfly statement ALONE in steady state (many generations of
+    workgroups: tools/stream_occupancy.hip), from the newest profiles/rNN_stream_occupancy.txt, or None."""
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_stream_occupancy.txt")))
+    if not found:
+        return None
+    rows, on = {}, False
+    for line in open(found[-1]):
+        if line.startswith("# steady state"):
+            on = True
+        elif on and line[:1].isdigit():
+            f = line.split()
+            rows[int(f[0])] = float(f[1])
+    return {"cycles_per_butterfly_by_waves_per_simd": rows, "source": os.path.relpath(found[-1], ROOT)} if rows else None
+
+
+def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, stream_counts=None, statement=None):
+    """The vector-ALU roofline of the forward transform on the unit's MEASURED throughput (tools/hw.py, profiles/r05_valu_peak.txt:
+    4 cycles per wave64 instruction for the VOP3-class forms the butterfly statements are made of -- SGPR-pair carries, 64-bit compare,
+    select by SGPR pair, v_mad_u64_u32 -- 2 cycles for plain moves and adds):
+      peak cycles per butterfly = stream's VOP3-class instructions x 4 + its moves x 2 + (SQ_INSTS_VALU per butterfly - stream length) x 4
+      frac_of_peak_at_held_clock = peak cycles per butterfly x wave-butterflies / (SIMDs x the launch's shader cycles): clock-free
+    stream_counts = [(VALU per butterfly of the statement, of which plain)] per pass (stream_plain_counts); None prices EVERY counted
+    instruction at 4 cycles (an upper estimate).  statement = statement_steady_state(): what the statement alone sustains."""
     n = 1 << logn
-    cpi = VALU_PEAK_CYCLES_PER_WAVE_INSTR
     bf = [batch * (n // 2) * stages for _, _, stages in passes]            # butterflies per launch of each pass
     ipb = [e[1]["valu_instr_per_butterfly"] for e in sq_entries]          # SQ_INSTS_VALU / wave-butterflies, forward kernels
     mean_ipb = sum(i * b for i, b in zip(ipb, bf)) / sum(bf)
@@ -269,59 +288,54 @@ def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, issue_model=None
     waves = [e[1].get("mean_waves_per_simd") for e in sq_entries]
     stall = [e[1].get("wave_issue_stall_frac") for e in sq_entries]
     achieved = sum(bf) / (sum(per_pass_ms) * 1e-3)
+    plain = [min(i, sc[1]) for i, sc in zip(ipb, stream_counts)] if stream_counts else [0.0] * len(ipb)
+    peak_cyc = [valu_peak_cycles(i, pl) for i, pl in zip(ipb, plain)]     # SIMD cycles one wave-butterfly needs at the unit's throughput
+    mean_peak_cyc = sum(c * b for c, b in zip(peak_cyc, bf)) / sum(bf)
 
-    def peak(f_ghz, instr):
-        return SIMDS * f_ghz * 1e9 / (cpi * instr) * 64
+    def peak(f_ghz, cycles_per_bf):
+        return SIMDS * f_ghz * 1e9 / cycles_per_bf * 64
 
     out = {
-        "instr_per_butterfly": ipb, "instr_per_butterfly_mean": mean_ipb,
-        "peak_cycles_per_wave_instr": cpi,
-        "peak_butterflies_per_s": peak(PEAK_CLOCK_GHZ, mean_ipb), "peak_clock_GHz": PEAK_CLOCK_GHZ,
+        "instr_per_butterfly": ipb, "instr_per_butterfly_mean": mean_ipb, "plain_instr_per_butterfly": plain,
+        "peak_cycles_per_wave_instr": {"vop3_class": VALU_PEAK_CYCLES_VOP3, "plain_moves_adds": VALU_PEAK_CYCLES_PLAIN, "source": VALU_PEAK_SOURCE},
+        "peak_cycles_per_butterfly": peak_cyc,
+        "peak_butterflies_per_s": peak(PEAK_CLOCK_GHZ, mean_peak_cyc), "peak_clock_GHz": PEAK_CLOCK_GHZ,
         "achieved_butterflies_per_s": achieved,
-        "frac_of_peak_at_2.4GHz": achieved / peak(PEAK_CLOCK_GHZ, mean_ipb),
-        "frac_of_peak_at_2.4GHz_per_pass": [b / (t * 1e-3) / peak(PEAK_CLOCK_GHZ, i) for b, t, i in zip(bf, per_pass_ms, ipb)],
+        "frac_of_peak_at_2.4GHz": achieved / peak(PEAK_CLOCK_GHZ, mean_peak_cyc),
+        "frac_of_peak_at_2.4GHz_per_pass": [b / (t * 1e-3) / peak(PEAK_CLOCK_GHZ, c) for b, t, c in zip(bf, per_pass_ms, peak_cyc)],
         "kernels": [e[0] for e in sq_entries],
         "mean_waves_per_simd": waves, "wave_issue_stall_frac": stall,
-        "what": "instr_per_butterfly = SQ_INSTS_VALU of the FORWARD pass kernels / (butterflies / 64); peak = %d SIMDs x f / "
-                "(%g cycles x instr) x 64 lanes: a wave64 instruction takes %g cycles on a SIMD-32 (MI355X_MICROARCH.md; the probe "
-                "tools/valu_issue_cost measures 1.9-2.0 for the streams' VOP3 forms at 8 waves per SIMD); frac_of_peak_at_2.4GHz uses THIS "
-                "run's pass durations; frac_of_peak_at_held_clock is clock-free: instr x %g cycles x wave-butterflies / (SIMDs x "
-                "GRBM_GUI_ACTIVE/8) of the counter run, held_clock_GHz = GRBM_GUI_ACTIVE / 8 / duration of the same profiled launches; "
-                "issue_cost_at_kernel_occupancy prices the same instructions with the cycles they cost when only as many waves share a "
-                "SIMD as these kernels run (a property of the occupancy, not a peak)" % (SIMDS, cpi, cpi, cpi),
+        "what": "instr_per_butterfly = SQ_INSTS_VALU of the FORWARD pass kernels / (butterflies / 64); peak cycles per butterfly = its "
+                "VOP3-class instructions x %g cycles + its plain moves / adds x %g (MEASURED steady-state throughput of the forms, %s; "
+                "instructions the counter sees beyond the statement are priced as VOP3-class); peak = %d SIMDs x f / cycles per butterfly x 64 "
+                "lanes; frac_of_peak_at_2.4GHz uses THIS run's pass durations; frac_of_peak_at_held_clock is clock-free: peak cycles x "
+                "wave-butterflies / (SIMDs x GRBM_GUI_ACTIVE/8) of the counter run, held_clock_GHz = GRBM_GUI_ACTIVE / 8 / duration of the "
+                "same profiled launches" % (VALU_PEAK_CYCLES_VOP3, VALU_PEAK_CYCLES_PLAIN, VALU_PEAK_SOURCE, SIMDS),
     }
     if all(h for h in held) and all(c for c in cyc):
         out["held_clock_GHz"] = held
-        per_pass = [i * b / 64 * cpi / (SIMDS * c) for i, b, c in zip(ipb, bf, cyc)]
+        kcyc = [SIMDS * c / (b / 64) for b, c in zip(bf, cyc)]              # kernel cycles per wave-butterfly per SIMD
+        per_pass = [p / k for p, k in zip(peak_cyc, kcyc)]
         tot_cyc = sum(cyc)
+        out["kernel_cycles_per_wave_butterfly_per_simd"] = kcyc
         out["frac_of_peak_at_held_clock_per_pass"] = per_pass
-        out["frac_of_peak_at_held_clock"] = sum(i * b / 64 for i, b in zip(ipb, bf)) * cpi / (SIMDS * tot_cyc)
-        out["kernel_cycles_per_wave_butterfly_per_simd"] = [SIMDS * c / (b / 64) for b, c in zip(bf, cyc)]
+        out["frac_of_peak_at_held_clock"] = sum(p * b / 64 for p, b in zip(peak_cyc, bf)) / (SIMDS * tot_cyc)
         # the clock THIS run held, if a launch takes the same number of cycles as under the profiler
         out["clock_this_run_GHz_estimate"] = [c / (t * 1e6) for c, t in zip(cyc, per_pass_ms)]
-        if issue_model:
-            wcyc = [weighted_issue_cycles(m, i, issue_model["costs"], issue_model.get("overhead_cycles", cpi))
-                    for m, i in zip(issue_model["streams"], ipb)]
-            out["issue_cost_at_kernel_occupancy"] = {
-                "waves_per_simd_priced": issue_model.get("waves_per_simd"),
-                "class_cycles": issue_model["costs"], "stream_mix": [m["mix"] for m in issue_model["streams"]],
-                "overhead_cycles": issue_model.get("overhead_cycles", cpi), "source": issue_model.get("source"),
-                "measured_stream_cycles_per_butterfly": issue_model.get("measured_stream_cycles"),
-                "cycles_per_butterfly": wcyc,
-                "frac_of_kernel_cycles_per_pass": [w * b / 64 / (SIMDS * c) for w, b, c in zip(wcyc, bf, cyc)],
-                "frac_of_kernel_cycles": sum(w * b / 64 for w, b in zip(wcyc, bf)) / (SIMDS * tot_cyc),
-                "what": "the share of the kernels' cycles that the VALU instructions account for when each is priced at the issue "
-                        "cost measured at this occupancy; the remainder is LDS exchange, waits on memory and barriers",
-            }
+        if statement:
+            st = statement["cycles_per_butterfly_by_waves_per_simd"]
+            best = min(v for w, v in st.items() if w >= 4) if any(w >= 4 for w in st) else min(st.values())
+            out["statement_alone_steady_state"] = {
+                "cycles_per_butterfly_by_waves_per_simd": st, "cycles_per_butterfly_at_4_or_more_waves": best, "source": statement["source"],
+                "kernel_over_statement": [k / best for k in kcyc],
+                "what": "the forward butterfly statement alone (register-resident radix-8 rounds, many generations of workgroups): what the "
+                        "kernels' rounds could run at if exchanges, loads and stores cost nothing"}
         out["saturated"] = bool(out["frac_of_peak_at_held_clock"] >= SATURATED)
         wv = "/".join("%.1f" % w for w in waves) if all(w for w in waves) else "~4"
-        st = "/".join("%.2f" % x for x in stall) if all(x is not None for x in stall) else "n/a"
-        out["verdict"] = ("vector-ALU at %.0f %% of its SIMD-32 peak at the held clock: saturated, an instruction saved returns as time"
-                          % (100 * out["frac_of_peak_at_held_clock"]) if out["saturated"] else
-                          "vector-ALU at %.0f %% of its SIMD-32 peak at the held clock: NOT saturated -- with %s waves per SIMD a wave's own "
-                          "issue interval (6.8 cycles alone, 3.35 at four waves for the streams' VOP3 forms) is what limits, plus LDS "
-                          "exchange and memory waits (SQ_WAIT_INST_ANY %s of wave-cycles in the counter run)"
-                          % (100 * out["frac_of_peak_at_held_clock"], wv, st))
+        out["verdict"] = ("vector ALU at %.0f %% of its measured throughput at the held clock (%s waves per SIMD): %s"
+                          % (100 * out["frac_of_peak_at_held_clock"], wv,
+                             "saturated, an instruction saved returns as time" if out["saturated"] else
+                             "the largest single consumer of the kernels' cycles but not saturated -- LDS exchanges, loads / stores and waits take the rest"))
     return out
 
 
@@ -333,53 +347,27 @@ SATURATED = 0.95
 def decide_bound(pass_frac_of_copy, valu_frac_of_peak, waves=None, held_clock_GHz=None):
     """roofline.bound from the run's own numbers, never asserted:
       "hbm"        every pass streams at >= SATURATED (0.95) of the same-run device copy
-      "valu"       the vector ALU is at >= 0.95 of its SIMD-32 peak at the held clock
+      "valu"       the vector ALU is at >= 0.95 of its measured throughput (tools/hw.py) at the held clock
       "power-cap"  neither, and the kernels hold less than 0.9 of the 2.4 GHz peak clock: the board power cap (1400 W) is the
                    resource that is exhausted -- HBM traffic and VALU work both cost joules, and the clock is what gives
                    (profiles/rNN_power_probe.txt: the transform draws 1359-1397 W at 1.91-1.94 GHz, its VALU work alone 1132 W at
                    2.4 GHz, a copy of its bytes alone 1117 W; profiles/r05_ab_contig8w_bound.txt: +49 % resident waves return 2.9 %
-                   of a pass, so it is not per-wave issue latency)
+                   of a pass: the units are busy, not waiting on occupancy)
       "unsaturated" none of the above can be shown (no counters for these sources, or the clock is held): nothing is claimed
     Returns (bound, detail).  Pure arithmetic (CPU unit test)."""
     hb = min(pass_frac_of_copy) if pass_frac_of_copy else None
     if hb is not None and hb >= SATURATED:
         return "hbm", "every pass streams at >= %.2f of the same-run device copy" % hb
     if valu_frac_of_peak is not None and valu_frac_of_peak >= SATURATED:
-        return "valu", "vector ALU at %.2f of its SIMD-32 peak at the held clock" % valu_frac_of_peak
+        return "valu", "vector ALU at %.2f of its measured throughput at the held clock" % valu_frac_of_peak
     w = ("%.1f" % (sum(waves) / len(waves))) if waves and all(waves) else "~4"
-    what = "passes stream at %s of the device copy, vector ALU at %s of its SIMD-32 peak (%s waves per SIMD)" % (
+    what = "passes stream at %s of the device copy, vector ALU at %s of its measured throughput (%s waves per SIMD)" % (
         "%.2f" % hb if hb is not None else "n/a", "%.2f" % valu_frac_of_peak if valu_frac_of_peak is not None else "n/a (no counters for these sources)", w)
     clk = min(held_clock_GHz) if held_clock_GHz and all(held_clock_GHz) else None
     if clk is not None and clk < 0.9 * PEAK_CLOCK_GHZ:
         return ("power-cap", "neither roofline is saturated: %s; the kernels hold %.2f of %.1f GHz under the board power cap -- the energy of "
                 "the HBM traffic plus the VALU work is what is exhausted, not either unit" % (what, clk, PEAK_CLOCK_GHZ))
     return "unsaturated", "neither roofline is saturated: %s; no held-clock figure shows a power cap" % what
-
-
-def load_issue_model(passes, src_hash, waves_per_simd=4):
-    """Inputs of roofline.valu.issue_cost_at_kernel_occupancy, or (None, reason): the newest profiles/rNN_valu_issue_cost.json
-    (measured on the GPU box by tools/valu_issue_cost) and profiles/rNN_valu_mix.json (tools/valu_mix.py, stamped with the
-    kernel-source hash)."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import glob
-
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_valu_issue_cost.json")))  # a property of the chip, not
-    if not found:                                                                                  # of the sources: newest wins
-        return None, "profiles/rNN_valu_issue_cost.json absent"
-    cost_path = found[-1]
-    mix, why = tagged_profile("valu_mix", src_hash)
-    if mix is None:
-        return None, why
-    from valu_mix import class_costs
-
-    ic = json.load(open(cost_path))
-    costs = class_costs(ic, waves_per_simd)
-    # first pass: per-lane twiddles (VGPRs); column passes: wave-uniform twiddles (SGPRs)
-    streams = [mix["streams"]["gl_fwd_v" if kind == "contig" else "gl_fwd_s"] for kind, _, _ in passes]
-    meas = {k: v["cycles_per_butterfly"].get(str(waves_per_simd)) for k, v in ic.get("streams", {}).items()}
-    return {"costs": costs, "streams": streams, "overhead_cycles": costs.get("other", VALU_PEAK_CYCLES_PER_WAVE_INSTR),
-            "measured_stream_cycles": meas, "waves_per_simd": waves_per_simd,
-            "source": "%s at %d waves per SIMD + %s" % (os.path.relpath(cost_path, ROOT), waves_per_simd, why)}, None
 
 
 # ---- verification of a shard: every rank, every device --------------------------------------------------------------------
@@ -636,11 +624,8 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
         if d:
             ent, why = forward_counters(d, passes)
             if ent:
-                model, model_why = load_issue_model(passes, src_hash)
-                valu = valu_roofline(ent, passes, [float(v) for v in per_pass], batch, logn, issue_model=model)
-                if model is None:
-                    valu["issue_cost_at_kernel_occupancy"] = None
-                    valu["issue_cost_source"] = "not computed: " + model_why
+                valu = valu_roofline(ent, passes, [float(v) for v in per_pass], batch, logn, stream_counts=stream_plain_counts(passes),
+                                     statement=statement_steady_state())
             else:
                 valu_src += "; not quoted: " + why
     step_s = out["ms_per_step"] * 1e-3
@@ -660,8 +645,9 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
         "bound": bound, "bound_detail": bound_detail, "roofline_of_fields": "hbm",
         "bound_note": "achieved/peak/frac are the HBM roofline SURVEY 8(d) prescribes (algorithmic bytes over the spec peak); "
                       "frac_ceiling is what frac could reach at most with this pass count, frac_of_practical_hbm how close the step is "
-                      "to %d trips at the same-run device-copy rate; roofline.valu is the vector-ALU roofline on the SIMD-32 peak "
-                      "(2 cycles per wave64 instruction).  The board power cap (1400 W) sets the clock the kernels hold."
+                      "to %d trips at the same-run device-copy rate; roofline.valu is the vector-ALU roofline on the unit's MEASURED "
+                      "throughput (4 cycles per wave64 instruction for the statements' VOP3-class forms, 2 for plain moves: tools/hw.py).  The "
+                      "board power cap (1400 W) sets the clock the kernels hold."
                       % len(passes),
         "frac_ceiling": 1.0 / len(passes),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -789,14 +775,28 @@ def events_ms(torch, fn, stream, steps, warmup):
     return each[len(each) // 2], b0.elapsed_time(b1) / steps
 
 
+def config_plain_share(c):
+    """Share of plain moves / adds (2 cycles; the rest costs 4: tools/hw.py) among the VALU instructions of this configuration's
+    butterfly statement, from the generator's instruction lists (tools/valu_mix.py; no GPU)."""
+    from valu_mix import stream_mix
+
+    if c["wb"] == 8:
+        m = stream_mix("fwd" if c["p"] == GOLDILOCKS else "fwd64")
+    else:
+        m = stream_mix("fwd32:" + ("lazy" if c["p"] < (1 << 30) else "small" if c["p"] < (1 << 31) else "any"))
+    return m["mix"].get("plain", 0) / float(m["valu"])
+
+
 def config_roofline(cfg_key, c, op_ms, copy_ms, passes, src_hash):
     """bench.py's roofline keys for one BASELINE configuration (tools/configs.py): achieved = algorithmic bytes of one operation /
     time per operation; traffic and the vector-ALU fraction are quoted from profiles/rNN_<cfg>_pmc_traffic.json /
     _sq_counters.json (tools/collect_profiles.sh) only when their kernel-source hash equals this tree's."""
     from configs import algorithmic_bytes
-    from hw import valu_frac_of_peak
 
     alg = float(algorithmic_bytes(c))
+    plain = config_plain_share(c)
+    what = ("VALU wave-instructions per operation at their measured throughput (%g cycles, %.0f %% of them plain moves / adds at %g: %s) / "
+            "(1024 SIMDs x GRBM_GUI_ACTIVE / 8 per operation): clock-free" % (VALU_PEAK_CYCLES_VOP3, 100 * plain, VALU_PEAK_CYCLES_PLAIN, VALU_PEAK_SOURCE))
     achieved = alg / (op_ms * 1e-3) / 1e9
     pmc, pmc_src = tagged_profile("%s_pmc_traffic" % cfg_key, src_hash)
     sq, sq_src = tagged_profile("%s_sq_counters" % cfg_key, src_hash)
@@ -819,20 +819,19 @@ def config_roofline(cfg_key, c, op_ms, copy_ms, passes, src_hash):
                 ins = sum(e[1]["SQ_INSTS_VALU"] for e in ent)
                 cyc = sum(e[1]["kernel_cycles"] for e in ent)
                 valu = {"instr_per_butterfly": ins / (hs["batch"] * (1 << (hs["logn"] - 1)) * hs["logn"] / 64.0),
-                        "frac_of_peak_at_held_clock": valu_frac_of_peak(ins, cyc),
+                        "frac_of_peak_at_held_clock": valu_frac_of_peak(ins, cyc, plain),
                         "mean_waves_per_simd": [e[1].get("mean_waves_per_simd") for e in ent],
                         "held_clock_GHz": [e[1].get("held_clock_GHz") for e in ent], "kernels": [e[1]["short"] for e in ent],
-                        "what": "the headline's counters: the same two pass kernels at batch %d (fractions do not depend on the batch)" % hs["batch"]}
+                        "what": what + "; the headline's counters: the same two pass kernels at batch %d (fractions do not depend on the batch)" % hs["batch"]}
                 sq_src = hs_src + " -- the headline's launches of the same two kernels"
     if sq and sq["per_op"].get("kernel_cycles"):
         po = sq["per_op"]
         valu = {"instr_per_butterfly": po["valu_instr_per_butterfly"],
-                "frac_of_peak_at_held_clock": valu_frac_of_peak(po["valu_instr"], po["kernel_cycles"]),
+                "frac_of_peak_at_held_clock": valu_frac_of_peak(po["valu_instr"], po["kernel_cycles"], plain),
                 "mean_waves_per_simd": [k.get("mean_waves_per_simd") for k in sq["kernels"].values()],
                 "held_clock_GHz": [k.get("held_clock_GHz") for k in sq["kernels"].values()],
                 "kernels": [k["short"] for k in sq["kernels"].values()],
-                "what": "SQ_INSTS_VALU per operation x %g cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 per operation): clock-free, on the "
-                        "SIMD-32 peak" % VALU_PEAK_CYCLES_PER_WAVE_INSTR}
+                "what": what}
     # physical trips through HBM on the convention the algorithmic bytes use: a transform moves 2N words per pass; the product's
     # fused schedule (inverse column passes of a and b 4N, fused middle 3N, forward column pass 2N) moves exactly the 9N it is priced on
     ceiling = 1.0 if c["op"] == "polymul" else 1.0 / max(1, passes)

@@ -105,47 +105,69 @@ def test_verdict_fields_single_rank():
 
 
 def test_valu_roofline_arithmetic_on_a_synthetic_mix():
-    """roofline.valu on the SIMD-32 peak: a wave64 VALU instruction costs 2 cycles of a SIMD's throughput,
-    so 22 instructions per butterfly at 98.2 kernel cycles per wave-butterfly per SIMD is 44 / 98.2 = 0.448 of peak -- not the
-    0.9 a 4-cycle price claimed.  The occupancy-priced second figure (measured issue cost of each instruction class at the
-    kernels' 4 waves per SIMD) is reported under its own name and never as a peak."""
+    """roofline.valu on the unit's MEASURED throughput (tools/hw.py, profiles/r05_valu_peak.txt: 4 cycles per wave64 instruction for
+    the VOP3-class forms of the butterfly statements, 2 for plain moves / adds): the forward statement's 22 VALU (20 + 2 moves) cost
+    84 cycles at peak, the counter's extra instructions 4 each; at 103.0 / 104.9 kernel cycles per wave-butterfly per SIMD that is
+    0.86 / 0.81 -- rounds 1-4's flat 4-cycle price said 0.91, round 5's first re-base on the guide's 2 cycles said 0.45."""
     import bench
 
-    assert bench.VALU_PEAK_CYCLES_PER_WAVE_INSTR == 2.0 and bench.SIMDS == 1024
-    mix = {"valu": 22, "salu": 5, "mix": {"mad64": 4, "carry": 14, "cmp64": 1, "cndmask": 1, "plain": 2}}
-    costs = {"mad64": 3.35, "carry": 3.35, "cmp64": 3.35, "cndmask": 3.26, "plain": 1.59, "other": 3.26}
-    stream = 4 * 3.35 + 14 * 3.35 + 3.35 + 3.26 + 2 * 1.59
-    assert bench.weighted_issue_cycles(mix, 22.0, costs, overhead_cycles=3.26) == pytest.approx(stream)
-    assert bench.weighted_issue_cycles(mix, 23.5, costs, overhead_cycles=3.26) == pytest.approx(stream + 1.5 * 3.26)
-    assert bench.weighted_issue_cycles(mix, 21.0, costs) == pytest.approx(stream)  # never negative overhead
-    assert bench.weighted_issue_cycles({"valu": 1, "mix": {"unknown": 1}}, 1.0, costs) == pytest.approx(2.0)  # unpriced class: the peak price
+    assert (bench.VALU_PEAK_CYCLES_VOP3, bench.VALU_PEAK_CYCLES_PLAIN, bench.SIMDS) == (4.0, 2.0, 1024)
+    assert bench.valu_peak_cycles(22, 2) == 84.0 and bench.valu_peak_cycles(23.15, 2) == pytest.approx(88.6)
     passes = [("contig", 0, 8), ("col", 8, 8)]
+    assert bench.stream_plain_counts(passes) == [(22, 2), (22, 2)]  # from the generator's own instruction lists
     bf_waves = 4096 * 32768 * 8 / 64  # wave-butterflies per launch
-    cyc = [98.2 * bf_waves / 1024, 101.1 * bf_waves / 1024]  # round 4's counters: 98.2 / 101.1 cycles per wave-butterfly per SIMD
-    ent = [("k0", {"valu_instr_per_butterfly": 23.15, "held_clock_GHz": 1.90, "kernel_cycles": cyc[0], "mean_waves_per_simd": 3.7,
+    kc = [103.0, 104.9]               # round 5's counters: kernel cycles per wave-butterfly per SIMD
+    cyc = [k * bf_waves / 1024 for k in kc]
+    ent = [("k0", {"valu_instr_per_butterfly": 23.15, "held_clock_GHz": 1.98, "kernel_cycles": cyc[0], "mean_waves_per_simd": 3.7,
                    "wave_issue_stall_frac": 0.47}),
-           ("k1", {"valu_instr_per_butterfly": 22.20, "held_clock_GHz": 1.95, "kernel_cycles": cyc[1], "mean_waves_per_simd": 3.7,
+           ("k1", {"valu_instr_per_butterfly": 22.20, "held_clock_GHz": 2.02, "kernel_cycles": cyc[1], "mean_waves_per_simd": 3.6,
                    "wave_issue_stall_frac": 0.41})]
-    v = bench.valu_roofline(ent, passes, [0.83, 0.80], 4096, 16)
-    assert v["peak_cycles_per_wave_instr"] == 2.0
-    assert v["frac_of_peak_at_held_clock_per_pass"] == [pytest.approx(23.15 * 2 / 98.2), pytest.approx(22.20 * 2 / 101.1)]  # 0.47 / 0.44
-    assert v["frac_of_peak_at_held_clock"] == pytest.approx((23.15 + 22.20) * 2 / (98.2 + 101.1))
-    assert v["kernel_cycles_per_wave_butterfly_per_simd"] == [pytest.approx(98.2), pytest.approx(101.1)]
-    assert v["peak_butterflies_per_s"] == pytest.approx(1024 * 2.4e9 / (2 * 22.675) * 64)
-    assert v["saturated"] is False and "NOT saturated" in v["verdict"] and "3.7/3.7 waves" in v["verdict"]
-    assert "issue_cost_at_kernel_occupancy" not in v  # without a model nothing occupancy-priced is claimed
-    for old in ("frac_at_held_clock", "frac_at_held_clock_weighted", "frac_at_2.4GHz"):
-        assert old not in v  # the 4-cycle keys are gone, not aliased
-    model = {"costs": costs, "streams": [mix, mix], "overhead_cycles": 3.26, "waves_per_simd": 4, "source": "synthetic"}
-    w = bench.valu_roofline(ent, passes, [0.83, 0.80], 4096, 16, issue_model=model)
-    ic = w["issue_cost_at_kernel_occupancy"]
-    assert ic["waves_per_simd_priced"] == 4 and ic["cycles_per_butterfly"][0] == pytest.approx(stream + 1.15 * 3.26)
-    assert ic["frac_of_kernel_cycles_per_pass"][0] == pytest.approx((stream + 1.15 * 3.26) / 98.2)
-    assert ic["frac_of_kernel_cycles"] > w["frac_of_peak_at_held_clock"]  # dearer per instruction than the peak price
-    assert w["frac_of_peak_at_held_clock"] == v["frac_of_peak_at_held_clock"]  # ... which it never replaces
-    # a kernel that really sat at the peak would say so
-    fast = [(k, dict(e, kernel_cycles=e["valu_instr_per_butterfly"] * 2 / 0.97 * bf_waves / 1024)) for k, e in ent]
-    assert bench.valu_roofline(fast, passes, [0.4, 0.4], 4096, 16)["saturated"] is True
+    st = {"cycles_per_butterfly_by_waves_per_simd": {1: 143.8, 2: 97.2, 3: 96.6, 4: 82.6, 8: 81.0}, "source": "synthetic"}
+    v = bench.valu_roofline(ent, passes, [0.83, 0.80], 4096, 16, stream_counts=[(22, 2), (22, 2)], statement=st)
+    assert v["peak_cycles_per_wave_instr"]["vop3_class"] == 4.0 and v["peak_cycles_per_wave_instr"]["plain_moves_adds"] == 2.0
+    assert v["peak_cycles_per_butterfly"] == [pytest.approx(88.6), pytest.approx(84.8)]
+    assert v["frac_of_peak_at_held_clock_per_pass"] == [pytest.approx(88.6 / 103.0), pytest.approx(84.8 / 104.9)]  # 0.86 / 0.81
+    assert v["frac_of_peak_at_held_clock"] == pytest.approx((88.6 + 84.8) / (103.0 + 104.9))
+    assert v["kernel_cycles_per_wave_butterfly_per_simd"] == [pytest.approx(103.0), pytest.approx(104.9)]
+    assert v["peak_butterflies_per_s"] == pytest.approx(1024 * 2.4e9 / 86.7 * 64)
+    assert v["saturated"] is False and "not saturated" in v["verdict"] and "3.7/3.6 waves" in v["verdict"]
+    sa = v["statement_alone_steady_state"]
+    assert sa["cycles_per_butterfly_at_4_or_more_waves"] == 81.0 and sa["kernel_over_statement"] == [pytest.approx(103.0 / 81.0), pytest.approx(104.9 / 81.0)]
+    for old in ("frac_at_held_clock", "frac_at_held_clock_weighted", "frac_at_2.4GHz", "issue_cost_at_kernel_occupancy"):
+        assert old not in v  # earlier rounds' keys are gone, not aliased
+    # without the statement's mix EVERY counted instruction is priced at 4 cycles: an upper estimate
+    u = bench.valu_roofline(ent, passes, [0.83, 0.80], 4096, 16)
+    assert u["peak_cycles_per_butterfly"] == [pytest.approx(23.15 * 4), pytest.approx(22.2 * 4)] and "statement_alone_steady_state" not in u
+    assert u["frac_of_peak_at_held_clock"] > v["frac_of_peak_at_held_clock"]
+    # a kernel that really sat at the unit's throughput would say so
+    fast = [(k, dict(e, kernel_cycles=bench.valu_peak_cycles(e["valu_instr_per_butterfly"], 2) / 0.97 * bf_waves / 1024)) for k, e in ent]
+    assert bench.valu_roofline(fast, passes, [0.4, 0.4], 4096, 16, stream_counts=[(22, 2), (22, 2)])["saturated"] is True
+
+
+def test_statement_steady_state_is_parsed_from_the_probe_file(tmp_path, monkeypatch):
+    import bench
+
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r05_stream_occupancy.txt").write_text(
+        "# closed batch\n1  141.68  6.440  2.304  141.69\n4  72.21  3.282  2.395  92.43\n"
+        "# steady state: 12 generations of workgroups\n# waves/SIMD  cycles\n1  143.79  6.536  2.390\n4  82.64  3.756  2.372\n8  81.02  3.683  2.376\n")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    st = bench.statement_steady_state()
+    assert st["cycles_per_butterfly_by_waves_per_simd"] == {1: 143.79, 4: 82.64, 8: 81.02} and "r05_stream_occupancy.txt" in st["source"]
+    (prof / "r05_stream_occupancy.txt").unlink()
+    assert bench.statement_steady_state() is None
+
+
+def test_config_plain_share_comes_from_the_generator():
+    """The extra configurations' VALU fraction prices plain moves / adds at 2 cycles and the rest at 4: the share comes from the
+    generator's instruction lists (Goldilocks 2 of 22; a 32-bit prime's carry statement 1 of 11; a lazy prime's 5 of 9)."""
+    import bench
+
+    assert bench.config_plain_share({"wb": 8, "p": GOLD}) == pytest.approx(2 / 22)
+    assert bench.config_plain_share({"wb": 4, "p": 3221225473}) == pytest.approx(1 / 11)
+    assert bench.config_plain_share({"wb": 4, "p": 998244353}) == pytest.approx(5 / 9)
+    assert 0 < bench.config_plain_share({"wb": 8, "p": 0x3FFFFFEE00000001}) < 0.2
 
 
 def test_decide_bound_from_the_runs_numbers():
@@ -157,8 +179,8 @@ def test_decide_bound_from_the_runs_numbers():
     assert bench.decide_bound([0.97, 0.96], 0.46)[0] == "hbm"
     assert bench.decide_bound([0.88, 0.89], 0.96)[0] == "valu"
     assert bench.decide_bound([0.93, 0.91], 0.46, [3.7, 3.7], [1.98, 2.02])[0] == "power-cap"  # 0.9-0.95 of a copy is not "hbm": the label must not flip with the copy's own noise
-    b, why = bench.decide_bound([0.88, 0.89], 0.46, [3.7, 3.7], [1.95, 1.97])
-    assert b == "power-cap" and "0.88" in why and "0.46" in why and "3.7 waves" in why and "1.95" in why
+    b, why = bench.decide_bound([0.88, 0.89], 0.84, [3.7, 3.7], [1.95, 1.97])
+    assert b == "power-cap" and "0.88" in why and "0.84" in why and "3.7 waves" in why and "1.95" in why
     b, why = bench.decide_bound([0.88, 0.89], 0.46, [3.7, 3.7], [2.38, 2.39])  # the clock is held: no cap to blame
     assert b == "unsaturated"
     b, why = bench.decide_bound([0.88, 0.89], None)

@@ -392,8 +392,8 @@ def test_bench_quotes_only_matching_forward_counters():
         v = r["valu"]
         assert v is not None and all(20 < x < 26 for x in v["instr_per_butterfly"]) and 0 < v["frac_of_peak_at_held_clock"] < 1
         assert all("false" in k.split(",")[4] for k in v["kernels"])  # PassCfg<F, LOG_M, LOG_C, CONTIG, INV, ...>: INV == false
-        ic = v.get("issue_cost_at_kernel_occupancy")
-        if ic:  # the occupancy-priced figure rides on the same counters
-            assert 0 < ic["frac_of_kernel_cycles"] < 1.2 and len(ic["cycles_per_butterfly"]) == 2
+        sa = v.get("statement_alone_steady_state")
+        if sa:  # what the butterfly statement alone sustains (profiles/rNN_stream_occupancy.txt): the kernels cannot beat it
+            assert 60 < sa["cycles_per_butterfly_at_4_or_more_waves"] < 100 and all(k >= 1.0 for k in sa["kernel_over_statement"])
     else:
         assert r["traffic"] is None and r["valu"] is None and ("not quoted" in r["traffic_source"] or "absent" in r["traffic_source"])

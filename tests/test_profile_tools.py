@@ -133,11 +133,11 @@ def test_sq_summary_keeps_directions_apart(tmp_path):
     assert [e[1]["valu_instr_per_butterfly"] for e in ent] == [pytest.approx(22.9), pytest.approx(22.3)]
     v = bench.valu_roofline(ent, passes, [0.83, 0.82], 4096, 16)
     assert v["instr_per_butterfly"] == [pytest.approx(22.9), pytest.approx(22.3)]
-    assert v["peak_butterflies_per_s"] == pytest.approx(1024 * 2.4e9 / (2 * 22.6) * 64)  # SIMD-32: 2 cycles per wave64 instruction
+    assert v["peak_butterflies_per_s"] == pytest.approx(1024 * 2.4e9 / (4 * 22.6) * 64)  # no mix given: every instruction at the VOP3-class price of 4 cycles
     assert 0 < v["frac_of_peak_at_2.4GHz"] < 1 and 0 < v["frac_of_peak_at_held_clock"] <= 1
-    # the summary's own per-kernel figure is the same quotient
-    assert by_short["pass_contig_8_fwd"]["valu_frac_of_peak"] == pytest.approx(22.9 * wave_bf * 2 / (1024 * 1.6e6))
-    assert v["frac_of_peak_at_held_clock_per_pass"][0] == pytest.approx(by_short["pass_contig_8_fwd"]["valu_frac_of_peak"])
+    # the summary's own per-kernel figure is the same quotient (all instructions at 4 cycles: the upper estimate)
+    assert by_short["pass_contig_8_fwd"]["valu_frac_of_peak_all_vop3"] == pytest.approx(22.9 * wave_bf * 4 / (1024 * 1.6e6))
+    assert v["frac_of_peak_at_held_clock_per_pass"][0] == pytest.approx(by_short["pass_contig_8_fwd"]["valu_frac_of_peak_all_vop3"])
     # a summary holding ONLY inverse kernels (what round 2's traffic file was) yields nothing
     only_inv = {"kernels": {k: e for k, e in d["kernels"].items() if e["direction"] == "inv"}}
     ent, why = bench.forward_counters(only_inv, passes)

@@ -100,8 +100,9 @@ def summarize_sq(cfg_key, ops, sq_csv, src_hash=None):
                    "SQ_INSTS_SALU GRBM_GUI_ACTIVE of tools/config_profile.py; per kernel, means per launch; valu_instr_per_butterfly = "
                    "SQ_INSTS_VALU per operation / (butterflies this kernel runs per operation / 64): the product kernel runs three "
                    "LOG_M-stage networks per polynomial and its two word-by-word products count as overhead on those; SQ_* cycle "
-                   "counters are quad-cycles summed over waves; kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs; valu_frac_of_peak prices every VALU "
-                   "instruction at the 2 cycles a wave64 instruction takes on a SIMD-32 (tools/hw.py): the vector ALU's share of its peak")
+                   "counters are quad-cycles summed over waves; kernel_cycles = GRBM_GUI_ACTIVE / 8 XCDs; valu_frac_of_peak_all_vop3 prices every VALU "
+                   "instruction at the 4 cycles the VOP3-class forms take (measured: tools/hw.py; plain moves / adds cost 2: an upper estimate, "
+                   "bench.config_roofline refines it with the statement's mix)")
     out["kernels"] = {}
     tot_valu = tot_cyc = tot_bf = 0.0
     for key, d in sq.items():
@@ -129,7 +130,7 @@ def summarize_sq(cfg_key, ops, sq_csv, src_hash=None):
                     e["wave_issue_stall_frac"] = m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]
                 if "SQ_WAIT_ANY" in m:
                     e["wave_parked_frac"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]
-            e["valu_frac_of_peak"] = valu_frac_of_peak(m["SQ_INSTS_VALU"], cyc)
+            e["valu_frac_of_peak_all_vop3"] = valu_frac_of_peak(m["SQ_INSTS_VALU"], cyc)
             tot_cyc += cyc * per_op
         tot_valu += m["SQ_INSTS_VALU"] * per_op
         tot_bf += bf_op
@@ -137,7 +138,7 @@ def summarize_sq(cfg_key, ops, sq_csv, src_hash=None):
     out["per_op"] = {"valu_instr": tot_valu, "butterflies_in_profiled_kernels": tot_bf,
                      "valu_instr_per_butterfly": tot_valu / (tot_bf / 64.0) if tot_bf else None,
                      "kernel_cycles": tot_cyc,
-                     "valu_frac_of_peak": valu_frac_of_peak(tot_valu, tot_cyc) if tot_cyc else None}
+                     "valu_frac_of_peak_all_vop3": valu_frac_of_peak(tot_valu, tot_cyc) if tot_cyc else None}
     return out
 
 

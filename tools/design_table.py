@@ -49,8 +49,9 @@ def headline(spread):
     pa, ca = power("forward (L2 loads, no stores)", pp)
     pc, _ = power("copy (xor kernel)", pp)
     cb = d["cpu_baseline"]
-    ic = v.get("issue_cost_at_kernel_occupancy") or {}
-    cc = ic.get("class_cycles", {})
+    sa = v.get("statement_alone_steady_state") or {}
+    vp = [l.split() for l in open(P("%s_valu_peak.txt" % R)) if l[:2] == "v_"]
+    vpk = {l[0]: float(l[-1]) if l[0] not in ("v_pk_fma_f32", "v_fma_f32") else float(l[-2]) for l in vp}
     rk = d["ranks"][0]
     ps = json.load(open(P("%s_phase_stamps.json" % R)))
     sp = [p["split"] for p in ps["passes"]]
@@ -67,8 +68,9 @@ def headline(spread):
 | `frac_of_practical_hbm` | two trips at the same-run device-copy rate ({cp:.2f} TB/s) would take {pf:.3f} ms: the step is at **{fp:.2f}** of that |
 | `roofline.traffic` (PMC, forward kernels) | {tr:.3f} GB = {trr:.2f} × algorithmic: two trips, no over-fetch within a pass |
 | each pass's stream rate | {s0:.2f} / {s1:.2f} TB/s = {f0:.2f}–{f1:.2f} of peak = {c0:.2f}–{c1:.2f} of the same-process device copy |
-| `roofline.valu`: vector ALU on the **SIMD-32 peak** (a wave64 instruction = 2 cycles, `tools/hw.py`) | {ipb:.2f} VALU per butterfly ({i0:.2f} / {i1:.2f}); peak = 1024 SIMDs·f/(2·instr)·64 = {pk:.2f}e12 bf/s at 2.4 GHz; `frac_of_peak_at_held_clock` **{fh0:.2f} / {fh1:.2f}** per pass ({kc0:.1f} / {kc1:.1f} kernel cycles per wave-butterfly per SIMD, {h0:.2f}–{h1:.2f} GHz under the counter run, {w0:.1f} / {w1:.1f} waves per SIMD); {f24:.2f} at 2.4 GHz |
-| … the same instructions at the **issue cost of this occupancy** (`issue_cost_at_kernel_occupancy`: `{R}_valu_issue_cost.json` at 4 waves per SIMD, `{R}_valu_mix.json`; a property of the occupancy, never a peak) | VOP3 carry / compare / `v_mad_u64_u32` forms {cy:.2f} cycles per wave-instruction, plain moves {pl:.2f}; a butterfly {ic0:.1f} / {ic1:.1f} cycles ⇒ {icf:.2f} of the kernels' cycles |
+| the vector ALU's **measured** throughput (`{R}_valu_peak.txt`, `tools/valu_peak.hip`: launch duration × in-kernel clock ÷ wave-instructions per SIMD, 12 generations of workgroups) | `v_add_co_u32` {vadd:.2f}, `v_addc_co_u32` {vaddc:.2f}, `v_mad_u64_u32` {vmad:.2f}, `v_mul_lo_u32` {vmul:.2f}, `v_cndmask_b32` by SGPR pair {vcnd:.2f} cycles per wave64 instruction; `v_mov_b32` {vmov:.2f}, `v_add_u32` {vaddu:.2f}; sanity: `v_pk_fma_f32` {vpk:.2f} cycles = the data sheet's 157 TFLOP/s at 2.4 GHz. Nominal prices (`tools/hw.py`): **4 cycles** for the statements' VOP3-class forms, **2** for plain moves / adds |
+| `roofline.valu` on that throughput | {ipb:.2f} VALU per butterfly ({i0:.2f} / {i1:.2f}, 2 of them moves) = {pc0:.1f} / {pc1:.1f} cycles at peak; the kernels take {kc0:.1f} / {kc1:.1f} cycles per wave-butterfly per SIMD ({h0:.2f}–{h1:.2f} GHz under the counter run, {w0:.1f} / {w1:.1f} waves per SIMD): `frac_of_peak_at_held_clock` **{fh0:.2f} / {fh1:.2f}**; peak {pk:.2f}e12 bf/s at 2.4 GHz, {f24:.2f} of it in wall-clock terms |
+| … and the butterfly statement ALONE in steady state (`{R}_stream_occupancy.txt`, last table) | {st1:.0f} / {st2:.0f} / {st3:.0f} / {st4:.0f} / {st8:.0f} cycles per butterfly per SIMD at 1 / 2 / 3 / 4 / 8 resident waves: from four waves on it runs AT the unit's throughput ({stb:.0f} against 84 at nominal prices); the kernels take {ks0:.2f} / {ks1:.2f} × that |
 | **`roofline.bound` = `{bound}`** (decided by `bench.decide_bound` from these numbers) | {bd} |
 | what holds the clock | the 1400 W board cap: transform {pt:.0f} W at {ct:.2f} GHz; its VALU work alone (loads from L2, no stores) {pa:.0f} W at {ca:.2f} GHz; a copy of its bytes alone {pc:.0f} W (`profiles/{R}_power_probe.txt`) |
 | VALU floor (same kernels, loads from L2, no stores; measured in the bench run) | {fl0:.3f} + {fl1:.3f} ms (cycle view: `{R}_sq_real_vs_floor.txt`) |
@@ -87,9 +89,13 @@ def headline(spread):
            fh0=v["frac_of_peak_at_held_clock_per_pass"][0], fh1=v["frac_of_peak_at_held_clock_per_pass"][1],
            kc0=v["kernel_cycles_per_wave_butterfly_per_simd"][0], kc1=v["kernel_cycles_per_wave_butterfly_per_simd"][1],
            h0=min(v["held_clock_GHz"]), h1=max(v["held_clock_GHz"]), w0=v["mean_waves_per_simd"][0], w1=v["mean_waves_per_simd"][1],
-           cy=cc.get("carry", float("nan")), pl=cc.get("plain", float("nan")),
-           ic0=(ic.get("cycles_per_butterfly") or [float("nan")] * 2)[0], ic1=(ic.get("cycles_per_butterfly") or [float("nan")] * 2)[1],
-           icf=ic.get("frac_of_kernel_cycles", float("nan")), bound=r["bound"], bd=r["bound_detail"],
+           vadd=vpk["v_add_co_u32"], vaddc=vpk["v_addc_co_u32"], vmad=vpk["v_mad_u64_u32"], vmul=vpk["v_mul_lo_u32"], vcnd=vpk["v_cndmask_b32"],
+           vmov=vpk["v_mov_b32"], vaddu=vpk["v_add_u32"], vpk=vpk["v_pk_fma_f32"],
+           pc0=v["peak_cycles_per_butterfly"][0], pc1=v["peak_cycles_per_butterfly"][1],
+           st1=sa["cycles_per_butterfly_by_waves_per_simd"]["1"], st2=sa["cycles_per_butterfly_by_waves_per_simd"]["2"],
+           st3=sa["cycles_per_butterfly_by_waves_per_simd"]["3"], st4=sa["cycles_per_butterfly_by_waves_per_simd"]["4"],
+           st8=sa["cycles_per_butterfly_by_waves_per_simd"]["8"], stb=sa["cycles_per_butterfly_at_4_or_more_waves"],
+           ks0=sa["kernel_over_statement"][0], ks1=sa["kernel_over_statement"][1], bound=r["bound"], bd=r["bound_detail"],
            pt=pt, ct=ct, pa=pa, ca=ca, pc=pc, fl0=r["valu_floor_pass_ms"][0], fl1=r["valu_floor_pass_ms"][1],
            so0=100 * (ps["overhead"]["stamped_over_product"][0] - 1), so1=100 * (ps["overhead"]["stamped_over_product"][1] - 1),
            a0=share(0, "compute"), b0=share(0, "exchange"), c0_=share(0, "memory"), d0=share(0, "sync"), it0=ps["passes"][0]["iteration_cycles_mean_steady"],
@@ -104,7 +110,7 @@ def configs():
     rows = {c["config"].split(":")[0]: c for c in jl(P("%s_bench_all_configs.jsonl" % R))}
     head = jl(P("%s_bench.json" % R))[-1]
     line = {e["key"]: e for e in head["configs"]}
-    out = ["| config | time per operation | `frac` of 8 TB/s (ceiling) | HBM bytes, PMC (÷ algorithmic) | VALU per butterfly; × 2 cycles ÷ kernel cycles (SIMD-32 peak) | "
+    out = ["| config | time per operation | `frac` of 8 TB/s (ceiling) | HBM bytes, PMC (÷ algorithmic) | VALU per butterfly; at the unit's measured throughput ÷ kernel cycles | "
            "waves / SIMD; held clock | `bound` | verified in the line |", "|---|---|---|---|---|---|---|---|"]
 
     def row(name, t, r, verified):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Reduce a rocprofv3 --pmc SQ_* GRBM_GUI_ACTIVE counter_collection.csv of the bench command to per-kernel figures:
-VALU instructions per butterfly, mean waves per SIMD, VALU instruction count x 2 cycles (SIMD-32 peak, tools/hw.py) over the kernel cycles, stall split,
+VALU instructions per butterfly, mean waves per SIMD, VALU instruction count x 4 cycles (the measured throughput of the VOP3-class forms, tools/hw.py) over the kernel cycles, stall split,
 launch duration and the shader clock the kernel held (GRBM_GUI_ACTIVE / 8 XCDs / duration).
 usage: sq_summary.py counter_collection.csv [--batch 4096] [--logn 16] > profiles/rNN_sq_counters.json
 
@@ -10,7 +10,7 @@ import collections, csv, json, os, sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from hw import SIMDS, VALU_PEAK_CYCLES_PER_WAVE_INSTR, valu_frac_of_peak
+from hw import SIMDS, VALU_PEAK_CYCLES_VOP3, valu_frac_of_peak
 from kernel_key import parse_pass_kernel
 
 
@@ -30,11 +30,12 @@ def summarize(path, batch=4096, logn=16, min_grid=1000000, src_hash=None):
                    "SQ_INSTS_VALU GRBM_GUI_ACTIVE -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-valu-floor (one pass, 8 SQ "
                    "slots); SQ_* cycle counters are quad-cycles summed over waves; GRBM_GUI_ACTIVE is summed over the 8 XCDs; means over the "
                    "batch-%d launches (N = 2^%d: batch * N/2 * LOG_M butterflies per launch, %d SIMDs); one entry per kernel instantiation, "
-                   "keyed by the full PassCfg<...> argument list (INV = 5th argument); valu_frac_of_peak = SQ_INSTS_VALU x %g cycles per "
-                   "wave-instruction (a wave64 instruction on a SIMD-32: MI355X_MICROARCH.md, tools/hw.py) / (%d SIMDs x kernel cycles): the "
-                   "vector ALU's share of its own peak, clock-free (SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU on this counter set); "
+                   "keyed by the full PassCfg<...> argument list (INV = 5th argument); valu_frac_of_peak_all_vop3 = SQ_INSTS_VALU x %g cycles per "
+                   "wave-instruction (the MEASURED throughput of the VOP3-class forms, tools/hw.py; plain moves / adds cost 2, so this is an "
+                   "UPPER estimate: bench.py refines it with the statement's mix) / (%d SIMDs x kernel cycles), clock-free (SQ_ACTIVE_INST_VALU "
+                   "equals SQ_INSTS_VALU on this counter set); "
                    "held_clock_GHz = GRBM_GUI_ACTIVE / 8 / launch duration under the profiler"
-                   % (batch, logn, SIMDS, VALU_PEAK_CYCLES_PER_WAVE_INSTR, SIMDS),
+                   % (batch, logn, SIMDS, VALU_PEAK_CYCLES_VOP3, SIMDS),
            "batch": batch, "logn": logn, "kernels": {}}
     for k, v in acc.items():
         m = {c: sum(x) / len(x) for c, x in v.items() if not c.startswith("_")}
@@ -51,7 +52,7 @@ def summarize(path, batch=4096, logn=16, min_grid=1000000, src_hash=None):
             if "SQ_WAVE_CYCLES" in m:
                 m["mean_waves_per_simd"] = m["SQ_WAVE_CYCLES"] * 4 / cyc / SIMDS
             if "SQ_INSTS_VALU" in m:
-                m["valu_frac_of_peak"] = valu_frac_of_peak(m["SQ_INSTS_VALU"], cyc)
+                m["valu_frac_of_peak_all_vop3"] = valu_frac_of_peak(m["SQ_INSTS_VALU"], cyc)
         if "SQ_WAVE_CYCLES" in m:
             if "SQ_WAIT_ANY" in m:
                 m["wave_parked_frac"] = m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"]

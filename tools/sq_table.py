@@ -27,7 +27,7 @@ for key, v in acc.items():
         if "SQ_WAVE_CYCLES" in m:
             line += "  waves/SIMD %.2f" % (m["SQ_WAVE_CYCLES"] * 4 / cyc / 1024)
         if "SQ_INSTS_VALU" in m:
-            line += "  VALU x 2 cycles / kernel cycles (SIMD-32 peak) %.3f" % (m["SQ_INSTS_VALU"] * 2 / cyc / 1024)
+            line += "  VALU x 4 cycles / kernel cycles (measured VOP3-class throughput) %.3f" % (m["SQ_INSTS_VALU"] * 4 / cyc / 1024)
     print(line)
     if "SQ_WAVE_CYCLES" in m:
         wc = m["SQ_WAVE_CYCLES"]

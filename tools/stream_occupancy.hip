@@ -25,7 +25,9 @@ struct Stamp {
 // UNROLL: how many radix-8 rounds one loop iteration holds as straight-line code (1: 6 statements, 2.7 KB -- every wave of the CU runs
 // the same few cache lines; 8: 48 statements, ~21 KB -- the footprint of a pass kernel's batch loop, and waves drift apart in it).
 // Same work per launch either way: does the statement slow down when the instruction stream is long?
-template <int UNROLL>
+// PRIO: 0 = every wave at the default priority; 1 = s_setprio(hardware wave slot & 3): the waves that share a SIMD get DIFFERENT static
+// priorities (does breaking the symmetry of the issue arbitration remove the even-occupancy penalty?)
+template <int UNROLL, int PRIO = 0>
 __global__ void __launch_bounds__(256, 8) k_round8(uint32_t *out, Stamp *st, int iters, uint32_t seed) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using namespace ntt;
@@ -35,6 +37,16 @@ __global__ void __launch_bounds__(256, 8) k_round8(uint32_t *out, Stamp *st, int
     for (int i = 0; i < 8; i++) a[i] = ((uint64_t) (threadIdx.x * 2654435761u + seed * (i + 3)) << 21 | (i * 1315423911u)) % P;
 #pragma unroll
     for (int i = 0; i < 7; i++) t[i] = ((((uint64_t) (seed * 40503u + i * 97u) << 29) | (i * 2246822519u + seed)) + threadIdx.x) % P;
+    if (PRIO) {
+        uint32_t hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        switch (hw_id & 3u) {  // WAVE_ID[1:0]: the slot of this wave on its SIMD
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
     const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
@@ -77,20 +89,21 @@ int main() {
     hipMalloc(&d_st, max_threads / 64 * sizeof(Stamp));
     std::vector<Stamp> h(max_threads / 64);
     struct V { const char *name; void (*k)(uint32_t *, Stamp *, int, uint32_t); int unroll; };
-    const V variants[] = {{"loop body = 1 round (2.7 KB)", k_round8<1>, 1}, {"loop body = 4 rounds (~11 KB)", k_round8<4>, 4}, {"loop body = 8 rounds (~21 KB)", k_round8<8>, 8}};
+    const V variants[] = {{"loop body = 1 round (2.7 KB)", k_round8<1>, 1}, {"loop body = 4 rounds (~11 KB)", k_round8<4>, 4}, {"loop body = 8 rounds (~21 KB)", k_round8<8>, 8},
+                          {"loop body = 1 round, s_setprio(wave slot & 3)", k_round8<1, 1>, 1}};
     for (const V &v : variants) {
         auto kern = v.k;
         hipFuncAttributes fa;
         hipFuncGetAttributes(&fa, (const void *) kern);
         printf("# gl_fwd2_v_w as register-resident radix-8 rounds (12 butterflies each, %d per wave), %s; kernel: %d VGPRs\n", ITERS, v.name, fa.numRegs);
-        printf("# waves/SIMD  cycles per butterfly per SIMD  cycles per VALU instruction (22)  clock GHz\n");
+        printf("# waves/SIMD  cycles per butterfly per SIMD (median wave)  cycles per VALU instruction (22)  clock GHz  cycles per butterfly per SIMD (99th-percentile wave)\n");
         for (int w = 1; w <= 8; w++) {
             const int blocks = CUS * w;
             const size_t lds = (160 * 1024 / w) - 512;
             if (hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) return 1;
             for (int k = 0; k < 2; k++) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_out, d_st, ITERS, 12345u + k);
             hipDeviceSynchronize();
-            std::vector<double> cyc, ghz;
+            std::vector<double> cyc, ghz, cmax;
             for (int r = 0; r < 5; r++) {
                 hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_out, d_st, ITERS, 777u + r);
                 hipDeviceSynchronize();
@@ -102,14 +115,65 @@ int main() {
                 std::nth_element(t.begin(), t.begin() + nw / 2, t.end());
                 cyc.push_back((double) c[nw / 2]);
                 ghz.push_back((double) c[nw / 2] / ((double) t[nw / 2] * 10.0));
+                // the 99th percentile of the waves' durations: with unequal priorities the waves of a SIMD finish one after the other,
+                // and the SIMD's throughput is set by the LAST one (every wave starts at the same time: one generation)
+                std::nth_element(c.begin(), c.begin() + (nw * 99) / 100, c.end());
+                cmax.push_back((double) c[(nw * 99) / 100]);
             }
             if (hipGetLastError() != hipSuccess) return 2;
             std::sort(cyc.begin(), cyc.end());
             std::sort(ghz.begin(), ghz.end());
+            std::sort(cmax.begin(), cmax.end());
             // wave w of a workgroup skips its first w iterations of the long body: median wave (1.5 skipped) ~ the nominal count
             const double rounds = (v.unroll > 1) ? (double) (ITERS / v.unroll - 1.5) * v.unroll : (double) ITERS;
             const double per_bf = cyc[2] / (w * 12.0 * rounds);
-            printf("%d  %.2f  %.3f  %.3f\n", w, per_bf, per_bf / 22.0, ghz[2]);
+            printf("%d  %.2f  %.3f  %.3f  %.2f\n", w, per_bf, per_bf / 22.0, ghz[2], cmax[2] / (w * 12.0 * rounds));
+            fflush(stdout);
+        }
+    }
+    // ---- steady-state throughput: MANY generations of workgroups (as a pass kernel runs: a finished wave is replaced at once), W resident
+    // per SIMD; cycles per butterfly per SIMD = launch duration x clock / butterflies per SIMD.  The closed-batch figures above time ONE
+    // generation, whose slower waves finish alone: this is the number a long-running kernel sees.
+    {
+        auto kern = k_round8<1>;
+        const int gens = 12, iters = 200;
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        Stamp *d_st2;
+        uint32_t *d_out2;
+        hipMalloc(&d_st2, (size_t) CUS * 8 * gens * 4 * sizeof(Stamp));
+        hipMalloc(&d_out2, (size_t) CUS * 8 * gens * 256 * sizeof(uint32_t));
+        std::vector<Stamp> h2((size_t) CUS * 8 * gens * 4);
+        printf("# steady state: %d generations of workgroups, %d rounds per wave, W resident per SIMD (LDS-forced)\n", gens, iters);
+        printf("# waves/SIMD  cycles per butterfly per SIMD (launch duration x clock / work)  cycles per VALU instruction (22)  clock GHz\n");
+        for (int w = 1; w <= 8; w++) {
+            const int blocks = CUS * w * gens;
+            const size_t lds = (160 * 1024 / w) - 512;
+            if (hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) return 1;
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_out2, d_st2, iters, 99u);
+            hipDeviceSynchronize();
+            std::vector<double> per;
+            double ghz = 0;
+            for (int r = 0; r < 5; r++) {
+                hipEventRecord(e0, 0);
+                hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, 0, d_out2, d_st2, iters, 777u + r);
+                hipEventRecord(e1, 0);
+                hipEventSynchronize(e1);
+                float ms = 0;
+                hipEventElapsedTime(&ms, e0, e1);
+                const size_t nw = (size_t) blocks * 4;
+                hipMemcpy(h2.data(), d_st2, nw * sizeof(Stamp), hipMemcpyDeviceToHost);
+                std::vector<double> g(nw);
+                for (size_t i = 0; i < nw; i++) g[i] = (double) h2[i].cycles / ((double) h2[i].ticks * 10.0);
+                std::nth_element(g.begin(), g.begin() + nw / 2, g.end());
+                ghz = g[nw / 2];
+                const double bf_per_simd = (double) blocks * 4 * 12.0 * iters / (CUS * 4.0);
+                per.push_back(ms * 1e-3 * ghz * 1e9 / bf_per_simd);
+            }
+            if (hipGetLastError() != hipSuccess) return 2;
+            std::sort(per.begin(), per.end());
+            printf("%d  %.2f  %.3f  %.3f\n", w, per[2], per[2] / 22.0, ghz);
             fflush(stdout);
         }
     }

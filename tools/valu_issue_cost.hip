@@ -1,3 +1,8 @@
+// NOTE (round 5): the "cycles" this tool prints are the MEDIAN wave's own cycle count of a ONE-generation launch divided by (waves per SIMD x
+// instructions) -- they presume that every wave of the launch runs side by side from start to end, which does not hold (its own "ns" column, wall
+// clock, says 4.3 cycles where "cycles" says 1.99).  They are a per-wave figure (useful at ONE wave: the pipeline's issue interval), NOT a throughput:
+// tools/valu_peak.hip measures the throughput (4 cycles per VOP3-class form, 2 per plain move / add) and tools/hw.py prices the rooflines on it.
+//
 // valu_issue_cost.hip -- issue cost, in SHADER CYCLES per wave-instruction per SIMD, of every VALU form the Goldilocks
 // butterfly streams (csrc/gl_asm.h) are made of (1 .. 8 waves per SIMD), and of the streams themselves (1 .. 4: they pin v104+).
 //

@@ -47,7 +47,11 @@ def classify(text: str, twiddle_in_sgpr: bool = False) -> str | None:
 def stream_mix(kind: str, twiddle_in_sgpr: bool = False) -> dict:
     import gen_gl_asm as G
 
-    ins = G.butterfly(kind, 0) if kind in ("fwd", "inv", "mul", "invs") else G.butterfly64(kind, 0)
+    if "32:" in kind:  # 4-byte words: kind "fwd32:any" | "fwd32:small" | "fwd32:lazy" (and inv32 / mul32)
+        k, mode = kind.split(":")
+        ins = G.butterfly32(k, 0, mode, G.M32_VBASE)
+    else:
+        ins = G.butterfly(kind, 0) if kind in ("fwd", "inv", "mul", "invs") else G.butterfly64(kind, 0)
     mix = collections.Counter()
     salu = 0
     for i in ins:
