@@ -37,6 +37,8 @@ profiles)
     timeout -k 10 300 python3 tools/phase_stamps.py --trace-prefix $S/trace/trace_mi355x_n16 --trace-cycles 150000 > $S/${TAG}_phase_stamps.json 2> gpurun_out/stamps.err || tail -3 gpurun_out/stamps.err
     timeout -k 10 300 python3 tools/phase_stamps.py --logn 12 --p 3221225473 --g 5 --word-bytes 4 --batch 1024 --shape 4,0,8,512 > $S/${TAG}_phase_stamps_cfg2.json 2>> gpurun_out/stamps.err || tail -3 gpurun_out/stamps.err
   fi
+  # the vector ALU's throughput per instruction form: the price list of tools/hw.py (tools/valu_peak.hip, built HERE)
+  if [ -x tools/valu_peak ]; then timeout -k 10 200 tools/valu_peak > $S/${TAG}_valu_peak.txt 2>&1 || true; fi
   # the butterfly statement against occupancy, 1 .. 8 waves per SIMD (tools/stream_occupancy.hip, built HERE)
   if [ -x tools/stream_occupancy ]; then timeout -k 10 200 tools/stream_occupancy > $S/${TAG}_stream_occupancy.txt 2>&1 || true; fi
   python3 tools/bench_configs.py > $S/${TAG}_bench_all_configs.jsonl 2> gpurun_out/cfg.err || true
