@@ -1,0 +1,44 @@
+"""Round 5 on the GPU: the price list the rooflines are computed on is a MEASUREMENT of this box, not a constant from a document.
+tools/hw.py says 4 cycles per wave64 instruction for the VOP3-class forms of the butterfly statements and 2 for plain moves / adds;
+tools/valu_peak (built by __graft_entry__.build()) measures them -- steady state, launch duration x in-kernel clock / wave-instructions
+per SIMD -- and its v_pk_fma_f32 row must reproduce the chip's published FP32 vector peak, which pins the method itself."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_valu_price_list_is_what_this_gpu_measures():
+    import hw
+
+    exe = os.path.join(ROOT, "tools", "valu_peak")
+    if not os.path.exists(exe):
+        pytest.skip("tools/valu_peak not built (a measurement tool: __graft_entry__.build() builds it best-effort)")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    rows = {}
+    for line in out.stdout.splitlines():
+        if line.startswith("v_"):
+            f = line.split()
+            name = f[0]
+            nums = [x for x in f[1:] if x.replace(".", "", 1).isdigit()]
+            # columns: ns, clock GHz, cycles[, TFLOP/s]
+            rows[name] = {"ns": float(nums[-4] if name in ("v_pk_fma_f32", "v_fma_f32") else nums[-3]),
+                          "ghz": float(nums[-3] if name in ("v_pk_fma_f32", "v_fma_f32") else nums[-2]),
+                          "cycles": float(nums[-2] if name in ("v_pk_fma_f32", "v_fma_f32") else nums[-1])}
+    for name in ("v_add_co_u32", "v_addc_co_u32", "v_mad_u64_u32", "v_mul_lo_u32", "v_cndmask_b32"):
+        assert 0.93 * hw.VALU_PEAK_CYCLES_VOP3 < rows[name]["cycles"] < 1.10 * hw.VALU_PEAK_CYCLES_VOP3, (name, rows[name])
+    for name in ("v_mov_b32", "v_add_u32"):
+        assert 0.93 * hw.VALU_PEAK_CYCLES_PLAIN < rows[name]["cycles"] < 1.20 * hw.VALU_PEAK_CYCLES_PLAIN, (name, rows[name])
+    # the method against the data sheet: v_pk_fma_f32 = 4 FLOP per lane per instruction; at the peak clock that is the published 157.3 TFLOP/s
+    pk = rows["v_pk_fma_f32"]
+    tflops_at_peak_clock = 4 * 64 / pk["cycles"] * hw.PEAK_CLOCK_GHZ * 1e9 * hw.SIMDS / 1e12
+    assert 0.92 * 157.3 < tflops_at_peak_clock < 1.05 * 157.3, (pk, tflops_at_peak_clock)
+    assert 1.0 < rows["v_mov_b32"]["ghz"] < 2.6  # the in-kernel clock the cycles are computed with is a sane shader clock
