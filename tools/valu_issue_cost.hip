@@ -215,6 +215,8 @@ int main() {
     std::vector<Stamp> h_st(max_threads / 64);
 
     printf("{\n \"device\": \"%s\", \"gcn_arch\": \"%s\", \"compute_units\": %d,\n", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    printf(" \"caveat\": \"the cycles figures are the MEDIAN WAVE of a ONE-generation launch divided by an assumed co-residency: a per-wave figure, NOT "
+           "the unit's throughput (tools/valu_peak.hip measures that: 4 cycles per VOP3-class form, 2 per plain move / add; this file's own ns column agrees)\",\n");
     printf(" \"method\": \"cycles = median over waves of delta s_memtime around the loop / (waves per SIMD x instructions per wave); "
            "clock_GHz = delta s_memtime / delta s_memrealtime (100 MHz); occupancy forced by LDS size; %d iterations x 64 instructions "
            "(forms) or x 12 butterflies (streams)\",\n", ITERS);
