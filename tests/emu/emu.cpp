@@ -21,6 +21,19 @@
 using namespace ntt;
 using namespace ntt::host;
 
+// Which template families this translation unit instantiates (bit set = compiled in; a call into an absent family returns
+// EMU_ABSENT).  The ordinary build has them all; tests/test_emu_asan.py compiles one family per sanitizer executable so that
+// the instrumented builds run in parallel and finish in about a minute instead of six.
+//   0 Goldilocks forward   1 Goldilocks inverse   2 general 64-bit forward   3 general 64-bit inverse
+//   4 4-byte forward       5 4-byte inverse       6 / 7 / 8 fused product middle: Goldilocks / general 64-bit / 4-byte
+#ifndef EMU_PARTS
+#define EMU_PARTS 0x1FF
+#endif
+#define EMU_HAS(bit) (((EMU_PARTS) >> (bit)) & 1)
+enum { EMU_ABSENT = -100 };
+// non-zero: the LDS hazard tracker stays off (emu_set_tracking; the sanitizer sweep checks memory safety, test_emu.py hazards)
+static int g_no_track = 0;
+
 namespace {
 
 // LDS hazard tracker (pass.h: NTT_LDS_ACCESS).  epoch = number of WORKGROUP barriers so far.  A word may be read by a wave
@@ -214,7 +227,7 @@ int run_product_mid(int n, uint32_t batch, uint32_t target_wgs, const void *a_in
             memset(ex.tile.data(), 0xA5, ex.tile.size() * sizeof(W));
             ex.tr.reset(ex.tile.data(), ex.tile.size(), sizeof(W));
             ex.tr.what = "product pass";
-            ntt::lds_track() = &ex.tr;
+            ntt::lds_track() = g_no_track ? nullptr : &ex.tr;
             run_product_pass<CI, CF>(ex, aa, ab, af);
             ntt::lds_track() = nullptr;
         }
@@ -263,7 +276,7 @@ int run_cfg(const Erased &e) {
             memset(ex.tile.data(), 0xA5, ex.tile.size() * sizeof(W));
             ex.tr.reset(ex.tile.data(), ex.tile.size(), sizeof(W));
             ex.tr.what = Cfg::CONTIG ? "CONTIG pass" : "column pass";
-            ntt::lds_track() = &ex.tr;
+            ntt::lds_track() = g_no_track ? nullptr : &ex.tr;
             auto go = [&]() {
                 if constexpr (CAN_FOLD) {
                     if (sc) return run_pass<Cfg, EmuExec<Cfg>, -1, true>(ex, a);
@@ -334,9 +347,39 @@ int dispatch(bool contig, int log_m, const Erased &e) {
     }
 }
 
+// the pass of one family (see EMU_PARTS)
+int dispatch_family(bool m64, int word_bytes, bool inverse, bool contig, int log_m, const Erased &e) {
+    (void) contig; (void) log_m; (void) e;
+    if (m64) {
+#if EMU_HAS(2)
+        if (!inverse) return dispatch<FieldM64, false>(contig, log_m, e);
+#endif
+#if EMU_HAS(3)
+        if (inverse) return dispatch<FieldM64, true>(contig, log_m, e);
+#endif
+    } else if (word_bytes == 8) {
+#if EMU_HAS(0)
+        if (!inverse) return dispatch<FieldGL, false>(contig, log_m, e);
+#endif
+#if EMU_HAS(1)
+        if (inverse) return dispatch<FieldGL, true>(contig, log_m, e);
+#endif
+    } else {
+#if EMU_HAS(4)
+        if (!inverse) return dispatch<FieldM32, false>(contig, log_m, e);
+#endif
+#if EMU_HAS(5)
+        if (inverse) return dispatch<FieldM32, true>(contig, log_m, e);
+#endif
+    }
+    return EMU_ABSENT;
+}
+
 }  // namespace
 
 extern "C" {
+
+void emu_set_tracking(int on) { g_no_track = !on; }
 
 // Forward (inverse = 0) or exact inverse (inverse = 1, scaled by N^-1 when scale != 0)
 // of `batch` polynomials, host buffers, table T in plain form (N words).
@@ -414,16 +457,7 @@ int emu_transform(int word_bytes, int logn, uint64_t p, const void *T_plain, con
         e.s0 = passes[i].s0;
         e.variant = passes[i].contig ? (contig_variant ? contig_variant : passes[i].variant) : 0;
         e.do_scale = (inverse && scale && i == 0) ? 1 : 0;
-        int rc;
-        if (m64)
-            rc = inverse ? dispatch<FieldM64, true>(passes[i].contig, passes[i].log_m, e)
-                         : dispatch<FieldM64, false>(passes[i].contig, passes[i].log_m, e);
-        else if (word_bytes == 8)
-            rc = inverse ? dispatch<FieldGL, true>(passes[i].contig, passes[i].log_m, e)
-                         : dispatch<FieldGL, false>(passes[i].contig, passes[i].log_m, e);
-        else
-            rc = inverse ? dispatch<FieldM32, true>(passes[i].contig, passes[i].log_m, e)
-                         : dispatch<FieldM32, false>(passes[i].contig, passes[i].log_m, e);
+        const int rc = dispatch_family(m64, word_bytes, inverse != 0, passes[i].contig, passes[i].log_m, e);
         if (rc) return rc;
         cur = out;
     }
@@ -460,8 +494,7 @@ int emu_forward_product(int word_bytes, int logn, uint64_t p, const void *T_plai
         e.s0 = passes[i].s0;
         e.in2 = i == 0 ? in2 : nullptr;
         e.pw_scale = to_table_form(to_table_form(scale % p, p, word_bytes), p, word_bytes);
-        const int rc = word_bytes == 8 ? dispatch<FieldGL, false>(passes[i].contig, passes[i].log_m, e)
-                                       : dispatch<FieldM32, false>(passes[i].contig, passes[i].log_m, e);
+        const int rc = dispatch_family(false, word_bytes, false, passes[i].contig, passes[i].log_m, e);
         if (rc) return rc;
         cur = out;
     }
@@ -513,35 +546,39 @@ int emu_polymul_fused(int word_bytes, int logn, uint64_t p, const void *T_plain,
             e.out = buf;
             e.tw = ti;
             e.s0 = passes[i].s0;
-            const int rc = m64 ? dispatch<FieldM64, true>(passes[i].contig, passes[i].log_m, e)
-                           : word_bytes == 8 ? dispatch<FieldGL, true>(passes[i].contig, passes[i].log_m, e)
-                                             : dispatch<FieldM32, true>(passes[i].contig, passes[i].log_m, e);
+            const int rc = dispatch_family(m64, word_bytes, true, passes[i].contig, passes[i].log_m, e);
             if (rc) return rc;
         }
     const uint64_t ninv = powmod(p / 2 + 1, (uint64_t) logn, p);
     const uint64_t pw = to_table_form(to_table_form(ninv, p, word_bytes), p, word_bytes);
-    int rc = -1;
+    int rc = EMU_ABSENT;
     if (m64) {
+#if EMU_HAS(7)
         switch (m0) {
 #define PM(M) case M: rc = run_product_mid<ProductCfg<M, FieldM64>>(logn, batch, target_wgs, a, b, out, ti, tf, pw, e); break;
             PM(7) PM(8) PM(9) PM(10) PM(11) PM(12)
 #undef PM
             default: return -1;
         }
+#endif
     } else if (word_bytes == 8) {
+#if EMU_HAS(6)
         switch (m0) {
 #define PM(M) case M: rc = run_product_mid<ProductCfg<M>>(logn, batch, target_wgs, a, b, out, ti, tf, pw, e); break;
             PM(7) PM(8) PM(9) PM(10) PM(11) PM(12)
 #undef PM
             default: return -1;
         }
+#endif
     } else {
+#if EMU_HAS(8)
         switch (m0) {
 #define PM(M) case M: rc = run_product_mid<ProductCfgM32<M>>(logn, batch, target_wgs, a, b, out, ti, tf, pw, e); break;
             PM(5) PM(6) PM(7) PM(8) PM(9) PM(10) PM(11) PM(12) PM(13)
 #undef PM
             default: return -1;
         }
+#endif
     }
     if (rc) return rc;
     for (size_t i = 1; i < passes.size(); i++) {
@@ -549,9 +586,7 @@ int emu_polymul_fused(int word_bytes, int logn, uint64_t p, const void *T_plain,
         e.out = out;
         e.tw = tf;
         e.s0 = passes[i].s0;
-        rc = m64 ? dispatch<FieldM64, false>(passes[i].contig, passes[i].log_m, e)
-             : word_bytes == 8 ? dispatch<FieldGL, false>(passes[i].contig, passes[i].log_m, e)
-                               : dispatch<FieldM32, false>(passes[i].contig, passes[i].log_m, e);
+        rc = dispatch_family(m64, word_bytes, false, passes[i].contig, passes[i].log_m, e);
         if (rc) return rc;
     }
     return 0;
