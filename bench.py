@@ -124,10 +124,7 @@ def cpu_baseline(logn, p, table, rows_fn, batch, cpu_seconds=20.0, threads=None)
     rate_n = sample / tn
     best, used = (rate_n, cores) if rate_n >= rate_1 else (rate_1, 1)
     return {"value": best, "unit": "NTT/s", "cores": used, "kind": "port",
-            "sample": "rows 0..%d of the GPU's own resident input batch (copied back from the device), N=2^%d, on %d threads "
-                      "(%.2f s) -- every core available to this process: affinity mask %d%s; 1-thread rate %.1f NTT/s"
-                      % (sample - 1, logn, cores, tn, aff,
-                         (", cgroup CPU quota %.1f cores" % quota) if quota else ", no cgroup quota", rate_1),
+            "sample": "rows 0..%d of the GPU's own input batch, N=2^%d, %d threads, %.2f s" % (sample - 1, logn, cores, tn),
             "sample_rows": sample, "sample_is_gpu_input": True, "rows_beyond_gpu_batch": 0,
             "sample_rows_wanted_for_%ds" % int(cpu_seconds): want, "sample_capped_at_batch": bool(want > batch),
             "host_affinity_cores": aff, "host_cgroup_quota_cores": quota, "host_available_cores": avail, "threads_all_cores_leg": cores,
@@ -253,22 +250,37 @@ def stream_plain_counts(passes):
     return out
 
 
+def stream_source_hash():
+    """identity of what tools/stream_occupancy measures: the statement generator and the probe (16 hex digits)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("gen_gl_asm.py", "stream_occupancy.hip"):
+        h.update(open(os.path.join(ROOT, "tools", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def statement_steady_state():
     """{waves per SIMD: cycles per butterfly per SIMD} of the forward butterfly statement ALONE in steady state (many generations of
-    workgroups: tools/stream_occupancy.hip), from the newest profiles/rNN_stream_occupancy.txt, or None."""
+    workgroups: tools/stream_occupancy.hip), from the newest profiles/rNN_stream_occupancy.txt whose `# stream_src_hash` line equals
+    stream_source_hash() of this tree (tools/run_round.sh writes it), or None: a statement-alone figure that was not re-measured on
+    this tree's generator is not quoted."""
     import glob
 
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_stream_occupancy.txt")))
-    if not found:
-        return None
-    rows, on = {}, False
-    for line in open(found[-1]):
-        if line.startswith("# steady state"):
-            on = True
-        elif on and line[:1].isdigit():
-            f = line.split()
-            rows[int(f[0])] = float(f[1])
-    return {"cycles_per_butterfly_by_waves_per_simd": rows, "source": os.path.relpath(found[-1], ROOT)} if rows else None
+    want = stream_source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_stream_occupancy.txt")), reverse=True):
+        rows, on, stamped = {}, False, None
+        for line in open(path):
+            if line.startswith("# stream_src_hash"):
+                stamped = line.split()[-1]
+            elif line.startswith("# steady state"):
+                on = True
+            elif on and line[:1].isdigit():
+                f = line.split()
+                rows[int(f[0])] = float(f[1])
+        if stamped == want and rows:
+            return {"cycles_per_butterfly_by_waves_per_simd": rows, "source": os.path.relpath(path, ROOT)}
+    return None
 
 
 def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, stream_counts=None, statement=None):
@@ -283,7 +295,7 @@ def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, stream_counts=No
     bf = [batch * (n // 2) * stages for _, _, stages in passes]            # butterflies per launch of each pass
     ipb = [e[1]["valu_instr_per_butterfly"] for e in sq_entries]          # SQ_INSTS_VALU / wave-butterflies, forward kernels
     mean_ipb = sum(i * b for i, b in zip(ipb, bf)) / sum(bf)
-    held = [e[1].get("held_clock_GHz") for e in sq_entries]
+    held, held_note = sane_clocks([e[1].get("held_clock_GHz") for e in sq_entries])
     cyc = [e[1].get("kernel_cycles") for e in sq_entries]
     waves = [e[1].get("mean_waves_per_simd") for e in sq_entries]
     stall = [e[1].get("wave_issue_stall_frac") for e in sq_entries]
@@ -312,6 +324,8 @@ def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, stream_counts=No
                 "wave-butterflies / (SIMDs x GRBM_GUI_ACTIVE/8) of the counter run, held_clock_GHz = GRBM_GUI_ACTIVE / 8 / duration of the "
                 "same profiled launches" % (VALU_PEAK_CYCLES_VOP3, VALU_PEAK_CYCLES_PLAIN, VALU_PEAK_SOURCE, SIMDS),
     }
+    if held_note:
+        out["held_clock_GHz"], out["held_clock_note"] = held, held_note
     if all(h for h in held) and all(c for c in cyc):
         out["held_clock_GHz"] = held
         kcyc = [SIMDS * c / (b / 64) for b, c in zip(bf, cyc)]              # kernel cycles per wave-butterfly per SIMD
@@ -343,16 +357,69 @@ def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, stream_counts=No
 # from box to box (the copy's own rate moves 3 % between runs): a 0.9 threshold made the label flip between two runs of one build.
 SATURATED = 0.95
 
+# A held clock is GRBM_GUI_ACTIVE / 8 / the launch's duration.  For launches of a few microseconds the counter also sees the
+# command processor's work around the kernel, and the quotient comes out ABOVE the part's peak clock (round 5's line carried 3.30
+# GHz for config 2's 14 us launch): such a figure is not a clock.  It is nulled where the valu object is built, so the printed
+# line, decide_bound and DESIGN's table all see the same sanitised value.
+CLOCK_SANITY = 1.02  # tolerance on PEAK_CLOCK_GHZ
 
-def decide_bound(pass_frac_of_copy, valu_frac_of_peak, waves=None, held_clock_GHz=None):
+
+def sane_clocks(clocks):
+    """(clocks with impossible entries nulled, reason or None)"""
+    out = [h if (h and h <= PEAK_CLOCK_GHZ * CLOCK_SANITY) else None for h in clocks]
+    bad = any(h and h > PEAK_CLOCK_GHZ * CLOCK_SANITY for h in clocks)
+    return out, ("quotient above the %.1f GHz peak clock: the launch is too short for GRBM_GUI_ACTIVE / 8 to be the kernel's own cycles"
+                 % PEAK_CLOCK_GHZ) if bad else None
+
+
+# ---- the printed line: numbers, not commentary (the reference prints numbers, src/test.cpp:171-174) -------------------------
+# Keys that explain other keys.  `--explain` keeps them (tools/design_table.py and the counter-provenance tests read them); the
+# default line drops them, cuts provenance strings to the file they name and rounds nested floats to 6 significant digits, so
+# that the driver-run line stays below 6 KB.  What every key means: DESIGN.md section 4 ("Reading the line").
+PROSE_KEYS = {"what", "definition", "bound_note", "frac_of_practical_hbm_what", "verdict", "data_note"}
+TOP_LEVEL_EXACT = {"value", "ms_per_step", "butterflies_per_s", "ops_per_s_reference_convention"}
+
+
+def slim_line(out):
+    """the default line from the full one: no prose keys, short provenance, 6 significant digits below the top level"""
+    def short(k, v):
+        if k.endswith("_source") and isinstance(v, str):
+            for cut in (";", " -- ", " ("):
+                v = v.split(cut)[0]
+            return v[:96]
+        if k == "kernels" and isinstance(v, list):  # a kernel's identity = its PassCfg<...> argument list (tools/kernel_key.py)
+            import re
+
+            def ident(x):
+                m = re.search(r"PassCfg<([^<>]*)>", x)
+                return m.group(1) if m else x[:64]
+            return [ident(x) if isinstance(x, str) else x for x in v]
+        return v
+
+    def walk(o, top=False):
+        if isinstance(o, dict):
+            return {k: (v if (top and k in TOP_LEVEL_EXACT) else walk(short(k, v))) for k, v in o.items() if k not in PROSE_KEYS}
+        if isinstance(o, list):
+            return [walk(v) for v in o]
+        if isinstance(o, float):
+            return float("%.6g" % o)
+        return o
+
+    return walk(out, top=True)
+
+
+def emit(out, args):
+    print(json.dumps(out if getattr(args, "explain", False) else slim_line(out), separators=(",", ":")), flush=True)
+
+
+def decide_bound(pass_frac_of_copy, valu_frac_of_peak, waves=None, held_clock_GHz=None, weights=None):
     """roofline.bound from the run's own numbers, never asserted:
       "hbm"        every pass streams at >= SATURATED (0.95) of the same-run device copy
       "valu"       the vector ALU is at >= 0.95 of its measured throughput (tools/hw.py) at the held clock
-      "power-cap"  neither, and the kernels hold less than 0.9 of the 2.4 GHz peak clock: the board power cap (1400 W) is the
-                   resource that is exhausted -- HBM traffic and VALU work both cost joules, and the clock is what gives
-                   (profiles/rNN_power_probe.txt: the transform draws 1359-1397 W at 1.91-1.94 GHz, its VALU work alone 1132 W at
-                   2.4 GHz, a copy of its bytes alone 1117 W; profiles/r05_ab_contig8w_bound.txt: +49 % resident waves return 2.9 %
-                   of a pass: the units are busy, not waiting on occupancy)
+      "power-cap"  neither, and the kernels hold -- on the TIME-WEIGHTED mean over the operation's kernels (`weights`: their
+                   durations or cycles; plain mean without) -- less than 0.9 of the 2.4 GHz peak clock: one short kernel a few
+                   per cent under the threshold does not decide the label.  The clock is the COUNTER run's (serialised rocprofv3
+                   --pmc launches), said so in the detail; DESIGN.md section 4 has the power-probe evidence behind the name.
       "unsaturated" none of the above can be shown (no counters for these sources, or the clock is held): nothing is claimed
     Returns (bound, detail).  Pure arithmetic (CPU unit test)."""
     hb = min(pass_frac_of_copy) if pass_frac_of_copy else None
@@ -361,13 +428,16 @@ def decide_bound(pass_frac_of_copy, valu_frac_of_peak, waves=None, held_clock_GH
     if valu_frac_of_peak is not None and valu_frac_of_peak >= SATURATED:
         return "valu", "vector ALU at %.2f of its measured throughput at the held clock" % valu_frac_of_peak
     w = ("%.1f" % (sum(waves) / len(waves))) if waves and all(waves) else "~4"
-    what = "passes stream at %s of the device copy, vector ALU at %s of its measured throughput (%s waves per SIMD)" % (
-        "%.2f" % hb if hb is not None else "n/a", "%.2f" % valu_frac_of_peak if valu_frac_of_peak is not None else "n/a (no counters for these sources)", w)
-    clk = min(held_clock_GHz) if held_clock_GHz and all(held_clock_GHz) else None
+    what = "copy %s, valu %s, %s waves per SIMD" % (
+        "%.2f" % hb if hb is not None else "n/a", "%.2f" % valu_frac_of_peak if valu_frac_of_peak is not None else "n/a (no counters)", w)
+    clk = None
+    if held_clock_GHz and all(held_clock_GHz):
+        ws = list(weights) if weights and len(weights) == len(held_clock_GHz) and all(weights) else [1.0] * len(held_clock_GHz)
+        clk = sum(h * x for h, x in zip(held_clock_GHz, ws)) / sum(ws)
     if clk is not None and clk < 0.9 * PEAK_CLOCK_GHZ:
-        return ("power-cap", "neither roofline is saturated: %s; the kernels hold %.2f of %.1f GHz under the board power cap -- the energy of "
-                "the HBM traffic plus the VALU work is what is exhausted, not either unit" % (what, clk, PEAK_CLOCK_GHZ))
-    return "unsaturated", "neither roofline is saturated: %s; no held-clock figure shows a power cap" % what
+        return "power-cap", "neither unit saturated (%s); clock %.2f of %.1f GHz (counter run, time-weighted; lowest %.2f)" % (
+            what, clk, PEAK_CLOCK_GHZ, min(held_clock_GHz))
+    return "unsaturated", "neither unit saturated (%s); no held-clock figure shows a power cap" % what
 
 
 # ---- verification of a shard: every rank, every device --------------------------------------------------------------------
@@ -496,9 +566,17 @@ def self_launch(args, argv):
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv + ["--rdzv-file", rdzv], env=env,
                                           stdout=fo, stderr=fe, text=True))
         # a rank that dies (before or after the rendezvous) would leave the others waiting on it: the first non-zero exit ends
-        # the job -- the exact children started above are terminated, nothing is restarted
+        # the job -- the exact children started above are terminated, nothing is restarted.  A rank that HANGS instead of exiting
+        # is ended the same way when the job's wall-clock limit expires (NTT_BENCH_LAUNCH_TIMEOUT_S, default 1500 s: a default
+        # run takes a few minutes), and the parent exits 124 like timeout(1).
+        deadline = time.monotonic() + float(os.environ.get("NTT_BENCH_LAUNCH_TIMEOUT_S", "1500"))
+        timed_out = False
         while any(p.poll() is None for p in procs):
-            if any(p.poll() not in (None, 0) for p in procs):
+            timed_out = time.monotonic() > deadline
+            if timed_out or any(p.poll() not in (None, 0) for p in procs):
+                if timed_out:
+                    sys.stderr.write("bench.py: the %d-rank job did not finish within its wall-clock limit; terminating the ranks still "
+                                     "running: %s\n" % (args.gpus, [r for r, p in enumerate(procs) if p.poll() is None]))
                 for p in procs:
                     if p.poll() is None:
                         p.terminate()
@@ -523,16 +601,16 @@ def self_launch(args, argv):
     sys.stdout.write(outs[0][0] or "")
     sys.stdout.flush()
     bad = [c for c in codes if c > 0] or [1 for c in codes if c != 0]  # a rank's own exit code before "terminated by the parent"
+    if timed_out:
+        return 124
     return bad[0] if bad else 0
 
 
 def config_name(logn, batch, world):
     if logn == 16 and batch == 4096:
-        return "BASELINE config 3's forward leg = the headline metric (N=2^16 Goldilocks, batch 4096 on one MI355X)" + (
-            ", weak-scaled: 4096 per GPU" if world > 1 else "")
+        return "BASELINE config 3, forward leg (the headline metric)" + (", weak-scaled" if world > 1 else "")
     if logn == 16 and batch == 8192:
-        return ("BASELINE config 5 (N=2^16 Goldilocks, batch 65536 sharded across 8 MI355X = 8192 per GPU): %d GPU(s) x 8192 = %d "
-                "polynomials in this job" % (world, world * batch))
+        return "BASELINE config 5 (65536 rows over 8 GPUs = 8192 per GPU), %d GPU(s) here" % world
     return "off-headline shape (N=2^%d, %d per GPU)" % (logn, batch)
 
 
@@ -549,9 +627,9 @@ def base_line(args, logn, batch, world, value, elapsed, passes, table_broadcast,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic", "launch": launch,
-        "config": {"workload": "%s; N=2^%d forward NTT, p=2^64-2^32+1, make_roots table g=7, batch=%d per GPU (%d in the job), "
-                               "out-of-place, inputs resident in HBM, a[b][i] = splitmix64(0x9E3779B97F4A7C15 + b*N + i) mod p"
-                               % (config_name(logn, batch, world), logn, batch, batch * world),
+        "config": {"workload": "%s; forward NTT N=2^%d, p=2^64-2^32+1, table make_roots(g=7), batch %d per GPU (%d in the job), out of "
+                               "place, resident in HBM" % (config_name(logn, batch, world), logn, batch, batch * world),
+                   "data_note": "a[b][i] = splitmix64(0x9E3779B97F4A7C15 + b*N + i) mod p (SURVEY 8d)",
                    "baseline_config": (3 if (logn == 16 and batch == 4096) else 5 if (logn == 16 and batch == 8192) else None),
                    "batch_per_gpu": batch, "hbm_passes": len(passes),
                    "sharding": "contiguous batch rows per rank, no data-path collective",
@@ -634,7 +712,7 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
     # the clock the kernels hold: GRBM_GUI_ACTIVE / 8 / duration of the profiled launches (a measurement; clock_this_run_GHz_estimate,
     # the same cycles over THIS run's durations, is reported beside it)
     bound, bound_detail = decide_bound(pass_of_copy, vfrac, valu.get("mean_waves_per_simd") if valu else None,
-                                       valu.get("held_clock_GHz") if valu else None)
+                                       valu.get("held_clock_GHz") if valu else None, [float(v) for v in per_pass])
     # what this pass count can reach on THIS device: every trip at the rate a plain copy of the same bytes achieves here
     practical_ms = len(passes) * copy["ms"]
     out["roofline"] = {
@@ -822,6 +900,7 @@ def config_roofline(cfg_key, c, op_ms, copy_ms, passes, src_hash):
                         "frac_of_peak_at_held_clock": valu_frac_of_peak(ins, cyc, plain),
                         "mean_waves_per_simd": [e[1].get("mean_waves_per_simd") for e in ent],
                         "held_clock_GHz": [e[1].get("held_clock_GHz") for e in ent], "kernels": [e[1]["short"] for e in ent],
+                        "kernel_cycles": [e[1].get("kernel_cycles") for e in ent],
                         "what": what + "; the headline's counters: the same two pass kernels at batch %d (fractions do not depend on the batch)" % hs["batch"]}
                 sq_src = hs_src + " -- the headline's launches of the same two kernels"
     if sq and sq["per_op"].get("kernel_cycles"):
@@ -831,7 +910,14 @@ def config_roofline(cfg_key, c, op_ms, copy_ms, passes, src_hash):
                 "mean_waves_per_simd": [k.get("mean_waves_per_simd") for k in sq["kernels"].values()],
                 "held_clock_GHz": [k.get("held_clock_GHz") for k in sq["kernels"].values()],
                 "kernels": [k["short"] for k in sq["kernels"].values()],
+                "kernel_cycles": [k.get("kernel_cycles") for k in sq["kernels"].values()],
                 "what": what}
+    if valu:
+        # a clock above the part's peak is not a clock (sane_clocks): null it AND the fraction made of the same cycle count
+        valu["held_clock_GHz"], note = sane_clocks(valu["held_clock_GHz"])
+        if note:
+            valu["held_clock_note"] = note
+            valu["frac_of_peak_at_held_clock"] = None
     # physical trips through HBM on the convention the algorithmic bytes use: a transform moves 2N words per pass; the product's
     # fused schedule (inverse column passes of a and b 4N, fused middle 3N, forward column pass 2N) moves exactly the 9N it is priced on
     ceiling = 1.0 if c["op"] == "polymul" else 1.0 / max(1, passes)
@@ -841,9 +927,10 @@ def config_roofline(cfg_key, c, op_ms, copy_ms, passes, src_hash):
         bound, why = "latency", ("one generation of workgroups: a %.1f us launch is a workgroup's own load -> butterflies -> store chain, "
                                  "not a throughput limit" % (op_ms * 1e3))
     else:
+        clocks = [h for h in valu["held_clock_GHz"] if h] if valu else None
+        wts = [c for h, c in zip(valu["held_clock_GHz"], valu.get("kernel_cycles") or []) if h] if valu else None
         bound, why = decide_bound([of_copy] if of_copy else None, valu["frac_of_peak_at_held_clock"] if valu else None,
-                                  [w for w in valu["mean_waves_per_simd"] if w] if valu else None,
-                                  [h for h in valu["held_clock_GHz"] if h and h < 2.6] if valu else None)
+                                  [w for w in valu["mean_waves_per_simd"] if w] if valu else None, clocks, wts)
     return {"bound": bound, "bound_detail": why, "roofline_of_fields": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "frac_ceiling": ceiling,
             "traffic": traffic, "traffic_ratio_to_algorithmic": (traffic / alg if traffic else None), "traffic_source": pmc_src,
@@ -1045,7 +1132,7 @@ def run_single_process(args):
     out.update(fields)
     with torch.cuda.device(devs[0]), torch.cuda.stream(streams[0]):  # torch's own kernels (the device copy) on the launch stream too
         code = max(code, rank0_extras(torch, args, plan0, table, xs[0], ys[0], streams[0], passes, out, ndev))
-    print(json.dumps(out), flush=True)
+    emit(out, args)
     return code
 
 
@@ -1068,6 +1155,9 @@ def main():
                     help="skip the inverse-transform leg (counter collection: only forward kernels in the profile)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even for one rank: exercises the twiddle broadcast path")
+    ap.add_argument("--explain", action="store_true",
+                    help="keep the explanatory strings (what / definition / bound_note / full provenance) and full float precision in the "
+                         "line; the default line is numbers only, < 6 KB (DESIGN.md section 4 says what every key means)")
     ap.add_argument("--rdzv-file", default=None,
                     help="rendezvous through this file (torch.distributed FileStore) instead of MASTER_ADDR / MASTER_PORT: no TCP "
                          "port to agree on; what `python bench.py --gpus N` uses for the ranks it starts itself")
@@ -1177,7 +1267,7 @@ def main():
 
     if rank == 0:
         code = max(code, rank0_extras(torch, args, plan, eng.table, x, y, stream, passes, out, world))
-        print(json.dumps(out), flush=True)
+        emit(out, args)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -91,7 +91,10 @@ NTT_HD void stamp(E &ex, int k) {
 }
 constexpr int STAMPS_PER_ITER = 12;    // 2R + 4 <= 12 for R <= 4
 constexpr int STAMP_HEADER = 4;        // 0 s_memrealtime at start, 1 s_memtime at start, 2 HW_ID | XCC_ID << 32, 3 iterations completed
-constexpr int STAMP_RECORD = 128;      // 64-bit slots per wave: header + 8 iterations x 12 stamps, [126] s_memtime / [127] s_memrealtime at the end
+constexpr int STAMP_RECORD = 128;      // 64-bit slots per wave: header + 8 iterations x 12 stamps, [125] scratch, [126] s_memtime / [127] s_memrealtime at the end
+constexpr int STAMP_ITERS = 8;         // iterations a record has room for; later ones go to STAMP_SCRATCH (GpuExec::stamp)
+constexpr int STAMP_SCRATCH = STAMP_RECORD - 3;
+static_assert(STAMP_HEADER + STAMP_ITERS * STAMPS_PER_ITER <= STAMP_SCRATCH, "stamp record: header + iterations + scratch + two end slots");
 #if defined(NTT_PHASE_STAMPS)
 // every stamp is one more VMEM store of the wave: the LDS-DMA kernels' counted wait (phase_dma_wait) has to know how many of
 // them are younger than the prefetch -- stamps 2 .. 2R+3 of the iteration that issued it and stamp 0 of the next one

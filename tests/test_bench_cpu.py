@@ -149,13 +149,21 @@ def test_statement_steady_state_is_parsed_from_the_probe_file(tmp_path, monkeypa
 
     prof = tmp_path / "profiles"
     prof.mkdir()
-    (prof / "r05_stream_occupancy.txt").write_text(
-        "# closed batch\n1  141.68  6.440  2.304  141.69\n4  72.21  3.282  2.395  92.43\n"
-        "# steady state: 12 generations of workgroups\n# waves/SIMD  cycles\n1  143.79  6.536  2.390\n4  82.64  3.756  2.372\n8  81.02  3.683  2.376\n")
+    (tmp_path / "tools").mkdir()
+    (tmp_path / "tools" / "gen_gl_asm.py").write_text("# generator\n")
+    (tmp_path / "tools" / "stream_occupancy.hip").write_text("// probe\n")
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    body = ("# closed batch\n1  141.68  6.440  2.304  141.69\n4  72.21  3.282  2.395  92.43\n"
+            "# steady state: 12 generations of workgroups\n# waves/SIMD  cycles\n1  143.79  6.536  2.390\n4  82.64  3.756  2.372\n8  81.02  3.683  2.376\n")
+    # round 6: quoted only when the file is stamped with the hash of THIS tree's generator + probe (tools/run_round.sh writes the line)
+    (prof / "r05_stream_occupancy.txt").write_text(body)
+    assert bench.statement_steady_state() is None  # unstamped: not re-measured on this tree
+    (prof / "r06_stream_occupancy.txt").write_text("# stream_src_hash 0123456789abcdef\n" + body)
+    assert bench.statement_steady_state() is None  # stamped with another tree's hash
+    (prof / "r04_stream_occupancy.txt").write_text("# stream_src_hash %s\n" % bench.stream_source_hash() + body)
     st = bench.statement_steady_state()
-    assert st["cycles_per_butterfly_by_waves_per_simd"] == {1: 143.79, 4: 82.64, 8: 81.02} and "r05_stream_occupancy.txt" in st["source"]
-    (prof / "r05_stream_occupancy.txt").unlink()
+    assert st["cycles_per_butterfly_by_waves_per_simd"] == {1: 143.79, 4: 82.64, 8: 81.02} and "r04_stream_occupancy.txt" in st["source"]
+    (tmp_path / "tools" / "gen_gl_asm.py").write_text("# generator, changed\n")
     assert bench.statement_steady_state() is None
 
 
@@ -279,3 +287,69 @@ def test_stream_mix_comes_from_the_generator():
                     "c": {"class": "mad64", "cycles": {"4": 5.3, "8": 5.3}}, "d": {"class": "carry+salu", "cycles": {"4": 9.0, "8": 9.0}}}}
     assert valu_mix.class_costs(ic, 4) == {"carry": pytest.approx(4.2), "mad64": pytest.approx(5.3)}
     assert valu_mix.weighted_cycles({"carry": 2, "mad64": 1, "zzz": 1}, valu_mix.class_costs(ic, 4)) == pytest.approx(8.4 + 5.3 + 4.0)
+
+
+# ---- round 6: the line is numbers, not commentary; impossible clocks are nulled; a hung rank cannot hang the job ------------
+def test_sane_clocks_and_time_weighted_bound():
+    """A GRBM_GUI_ACTIVE / 8 / duration quotient above the part's 2.4 GHz is not a clock (round 5's line carried 3.30 GHz for a
+    14 us launch): nulled with a reason.  decide_bound weighs the kernels' clocks by their time: one short kernel a few per cent
+    under the threshold no longer decides `power-cap`, and the detail says the clock is the counter run's."""
+    import bench
+
+    clocks, note = bench.sane_clocks([3.2969])
+    assert clocks == [None] and "too short" in note
+    clocks, note = bench.sane_clocks([1.93, 1.97, None])
+    assert clocks == [1.93, 1.97, None] and note is None
+    assert bench.sane_clocks([2.41])[0] == [2.41]  # within the tolerance of the quotient itself
+    # config 4's shape in round 5: 2.07 / 2.14 / 2.24 GHz with the long middle kernel at 2.24 -- mean clock 2.19 >= 2.16: not a cap
+    b, why = bench.decide_bound([0.54], 0.83, [3.6, 3.9, 3.6], [2.07, 2.14, 2.24], [2.5, 2.4, 7.1])
+    assert b == "unsaturated" and "0.54" in why and "0.83" in why
+    # ... while the plain minimum would have said power-cap; equal weights still do when every kernel is low
+    assert bench.decide_bound([0.88, 0.89], 0.84, [3.7, 3.7], [1.95, 1.97], [0.85, 0.83])[0] == "power-cap"
+    b, why = bench.decide_bound([0.88, 0.89], 0.84, [3.7, 3.7], [1.95, 1.97])
+    assert b == "power-cap" and "counter run" in why and "1.95" in why
+
+
+def test_slim_line_drops_prose_keeps_numbers():
+    """bench.slim_line: the default line has no explanatory keys, provenance strings are cut to the file they name, nested floats
+    carry 6 significant digits, and the contract's top-level numbers are untouched."""
+    import json
+
+    import bench
+
+    full = {"metric": "m", "value": 2448329.4740061713, "ms_per_step": 1.6729774499253836, "unit": "NTT/s",
+            "config": {"workload": "w", "data_note": "a[b][i] = ..."},
+            "verification": {"round_trip_identical_all": True, "what": "x" * 300},
+            "roofline": {"bound": "power-cap", "bound_detail": "short", "bound_note": "y" * 500, "definition": "z" * 400,
+                         "frac": 0.32367429514351825, "pass_ms": [0.8301234567, 0.8171234567],
+                         "traffic_source": "profiles/r05_pmc_traffic.json (src_hash abc); forward kernels: " + "k" * 200,
+                         "valu": {"what": "v" * 600, "held_clock_GHz": [1.93, None],
+                                  "kernels": ["void ntt::(anonymous namespace)::pass_kernel<ntt::PassCfg<ntt::FieldGL, 8, 0, true, false, 15, 3, 8, true>, false>(ntt::PassArgs<...>)"]}},
+            "configs": [{"name": "c", "roofline": {"definition": "d" * 100, "frac": 0.29912345678}}]}
+    slim = bench.slim_line(full)
+    text = json.dumps(slim)
+    assert slim["value"] == full["value"] and slim["ms_per_step"] == full["ms_per_step"]
+    assert "what" not in slim["verification"] and "bound_note" not in slim["roofline"] and "definition" not in slim["roofline"]
+    assert "definition" not in slim["configs"][0]["roofline"] and "what" not in slim["roofline"]["valu"] and "data_note" not in slim["config"]
+    assert slim["roofline"]["frac"] == 0.323674 and slim["roofline"]["pass_ms"] == [0.830123, 0.817123] and slim["configs"][0]["roofline"]["frac"] == 0.299123
+    assert slim["roofline"]["traffic_source"] == "profiles/r05_pmc_traffic.json" and slim["roofline"]["bound_detail"] == "short"
+    assert slim["roofline"]["valu"]["kernels"] == ["ntt::FieldGL, 8, 0, true, false, 15, 3, 8, true"] and slim["roofline"]["valu"]["held_clock_GHz"] == [1.93, None]
+    assert len(text) < 900 and full["roofline"]["bound_note"] == "y" * 500  # the input is not modified
+
+
+def test_self_launch_ends_a_hung_job(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` starts its own ranks; a rank that hangs (instead of exiting) used to hang the parent for ever.
+    With the wall-clock limit the parent terminates exactly the children it started and exits 124."""
+    import argparse
+    import time
+
+    import bench
+
+    hang = tmp_path / "hang.py"
+    hang.write_text("import time, sys\nopen(sys.argv[-1] + '.started', 'a').close()\ntime.sleep(120)\n")
+    monkeypatch.setattr(bench, "__file__", str(hang))
+    monkeypatch.setenv("NTT_BENCH_ONE_DEVICE", "1")  # rehearsal: no device count is asked for
+    monkeypatch.setenv("NTT_BENCH_LAUNCH_TIMEOUT_S", "2")
+    t0 = time.monotonic()
+    rc = bench.self_launch(argparse.Namespace(gpus=2), [])
+    assert rc == 124 and time.monotonic() - t0 < 40

@@ -380,7 +380,8 @@ def test_bench_quotes_only_matching_forward_counters():
     from ntt_aie_amd import _lib
 
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
-                          "--no-valu-floor", "--no-inverse"], capture_output=True, text=True, timeout=600)
+                          "--no-valu-floor", "--no-inverse", "--explain"],  # --explain: the full provenance strings, not the slim line's file names
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     r = d["roofline"]

@@ -289,19 +289,38 @@ def test_bench_single_process_n_devices():
     assert out.returncode == 2 and d is None and "only" in out.stderr
 
 
+def _walk(o, path=""):
+    if isinstance(o, dict):
+        for k, v in o.items():
+            yield from _walk(v, path + "/" + k)
+    elif isinstance(o, list):
+        for i, v in enumerate(o):
+            yield from _walk(v, "%s[%d]" % (path, i))
+    else:
+        yield path, o
+
+
 def test_bench_json_contract_frac_step_and_gpu_input_sample():
     """The default line (N = 1): roofline.frac_step (bytes over the line's own ms_per_step, NOT clamped since round 5) stays within
-    3 % of frac (bytes over the kernels' hipEvent time) -- a step cannot be shorter than its kernels, beyond the clock the chip held
-    in each phase; the CPU baseline ran on the GPU's own input rows, never beyond the batch, and says so; the single rank verified
-    itself; BASELINE configs 2 and 4 are in the same line, each verified without the oracle (round 5)."""
+    8 % of frac (bytes over the kernels' hipEvent time) -- a step cannot be shorter than its kernels, beyond the clock the chip held
+    in each phase: the two are measured seconds apart under a power cap whose held clock moves by the run-to-run spread of the
+    device copy (3 % and more); the CPU baseline ran on the GPU's own input rows, never beyond the batch, and says so; the single
+    rank verified itself; BASELINE configs 2 and 4 are in the same line, each verified without the oracle (round 5).  Round 6: the
+    line is numbers, not commentary -- below 6 KB, no explanatory keys, and no clock above the part's 2.4 GHz anywhere in it."""
     out, d = _bench(["--steps", "5", "--warmup", "2", "--no-valu-floor", "--no-inverse", "--cpu-threads", "4"])
     assert out.returncode == 0 and d is not None, out.stdout[-1000:] + out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    assert len(line) < 6144, len(line)
+    leaves = list(_walk(d))
+    assert not [k for k, _ in leaves if k.rsplit("/", 1)[-1].split("[")[0] in ("what", "definition", "bound_note", "verdict")]
+    clocks = [v for k, v in leaves if "clock" in k and "GHz" in k and isinstance(v, (int, float))]
+    assert all(v <= 2.4 * 1.02 for v in clocks), clocks
     r = d["roofline"]
-    assert "frac_step_uncapped" not in r and 0 < r["frac_step"] <= r["frac"] * 1.03 and r["frac"] <= r["frac_ceiling"]
+    assert "frac_step_uncapped" not in r and 0 < r["frac_step"] <= r["frac"] * 1.08 and r["frac"] <= r["frac_ceiling"]
     assert abs(r["frac_step"] / r["frac"] - 1) < 0.15  # step time and summed kernel time describe the same launches (5 steps: the clock the chip holds in each phase moves them a few per cent apart)
-    assert abs(r["achieved_step"] - r["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9) / r["achieved_step"] < 1e-6
+    assert abs(r["achieved_step"] - r["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9) / r["achieved_step"] < 1e-5  # (6 digits)
     # the step against what two trips at this run's device-copy rate would take: a fraction of a floor, so below 1 up to clock noise
-    assert 0.5 < r["frac_of_practical_hbm"] < 1.05 and abs(r["practical_hbm_floor_ms"] - 2 * r["device_copy"]["ms"]) < 1e-9
+    assert 0.5 < r["frac_of_practical_hbm"] < 1.05 and abs(r["practical_hbm_floor_ms"] - 2 * r["device_copy"]["ms"]) < 1e-5 * r["practical_hbm_floor_ms"]
     assert r["bound"] in ("hbm", "valu", "power-cap", "unsaturated") and r["roofline_of_fields"] == "hbm" and r["bound_detail"]
     if r["valu"] is not None:  # counters of exactly these sources are committed: the vector ALU against its MEASURED throughput (tools/hw.py)
         v = r["valu"]
@@ -313,20 +332,20 @@ def test_bench_json_contract_frac_step_and_gpu_input_sample():
     assert c["sample_is_gpu_input"] is True and "GPU's own" in c["sample"] and c["kind"] == "port" and 16 <= c["sample_rows"] <= 4096
     assert c["rows_beyond_gpu_batch"] == 0
     assert d["all_ranks_verified"] is True and d["world_size_seen"] == 1 and d["ranks"][0]["rank"] == 0
-    assert d["launch"] == "process-per-gpu" and "r02_power_probe" not in r["bound_note"]
+    assert d["launch"] == "process-per-gpu"
     # configs 2 and 4, driver-observed: one entry each, verified, with the roofline keys of the headline
     assert [e["key"] for e in d["configs"]] == ["cfg2", "cfg4", "cfg5_shard"] and d["configs_all_verified"] is True
     c2, c4, c5 = d["configs"]
     assert c5["baseline_config"] == 5 and c5["batch"] == 8192 and c5["verified"] and c5["hbm_passes"] == 2 and c5["unit"] == "NTT/s"
     assert 0.5 * d["value"] < c5["value"] < 1.5 * d["value"]  # the shard runs at the headline's rate (twice the rows, twice the time)
     assert c2["baseline_config"] == 2 and c2["verified"] and c2["verification"]["round_trip_identical"] and c2["verification"]["coefficient_sum_invariant"]
-    assert c2["unit"] == "NTT/s" and 0 < c2["ms"] < 1.0 and abs(c2["value"] - 1024 / (c2["ms"] * 1e-3)) / c2["value"] < 1e-9
+    assert c2["unit"] == "NTT/s" and 0 < c2["ms"] < 1.0 and abs(c2["value"] - 1024 / (c2["ms"] * 1e-3)) / c2["value"] < 1e-5
     assert c4["baseline_config"] == 4 and c4["verified"] and c4["verification"]["evaluation_at_root_of_xN_plus_1"] and c4["verification"]["transform_domain_identity_whole_batch"]
     assert c4["unit"] == "products/s" and 1.0 < c4["ms"] < 100.0
     for e in (c2, c4, c5):
         rr = e["roofline"]
         assert 0 < rr["frac"] <= rr["frac_ceiling"] <= 1.0 and rr["peak"] == 8000.0 and rr["unit"] == "GB/s" and rr["bound"]
-        assert abs(rr["achieved"] - rr["algorithmic_bytes_per_op"] / (e["ms"] * 1e-3) / 1e9) / rr["achieved"] < 1e-9
+        assert abs(rr["achieved"] - rr["algorithmic_bytes_per_op"] / (e["ms"] * 1e-3) / 1e9) / rr["achieved"] < 1e-5
 
 
 # ---- the wide radix-8 variant of the 4-byte single-pass sizes (plan.h: PassDesc::variant 1) ---------------------------------

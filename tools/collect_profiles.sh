@@ -25,7 +25,7 @@ fi
 python3 $ROOT/tools/valu_mix.py > "$SUM/${TAG}_valu_mix.json" 2> /dev/null
 cp "$SUM/${TAG}_valu_mix.json" "$ROOT/profiles/"
 cd /tmp
-python3 $ROOT/bench.py > "$SUM/${TAG}_bench.json"
+python3 $ROOT/bench.py --explain > "$SUM/${TAG}_bench.json"   # the full line (explanatory keys kept: tools/design_table.py reads them); the driver runs the slim default
 tail -c 600 "$SUM/${TAG}_bench.json"; echo
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o run -- $BENCH > "$OUT/stats.log" 2>&1
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$SUM/${TAG}_kernel_stats.csv"
@@ -64,6 +64,6 @@ collect_config cfg4 10 3
 # the judged bench line once more, now that the counter summaries of THIS build exist (headline AND configs 2 / 4): bench.py quotes
 # roofline.traffic and the VALU counters only from profiles/<tag>_*.json stamped with the tree's kernel-source hash
 cd /tmp
-python3 $ROOT/bench.py > "$SUM/${TAG}_bench.json"
+python3 $ROOT/bench.py --explain > "$SUM/${TAG}_bench.json"   # the full line (explanatory keys kept: tools/design_table.py reads them); the driver runs the slim default
 tail -c 300 "$SUM/${TAG}_bench.json"; echo
 ls -la "$SUM"

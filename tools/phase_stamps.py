@@ -65,6 +65,8 @@ def reduce_region(recs, R, dma, log_m, e_words, nt):
     real = (live[:, REC - 1] - live[:, 0]).astype(np.float64)  # s_memrealtime: 100 MHz
     out["clock_GHz_median"] = float(np.median(life / np.maximum(1.0, real) * 0.1))
     out["iterations_per_wave"] = {"min": int(iters.min()), "median": float(np.median(iters)), "max": int(iters.max())}
+    if int(iters.max()) > 8:  # pass.h STAMP_ITERS: a record holds 8 iterations, the device stamps later ones into a scratch slot
+        out["iterations_recorded"] = "the first 8 of each wave; later iterations ran and were stamped into the record's scratch slot"
     out["wave_lifetime_cycles_median"] = float(np.median(life))
     # the launch on the 100 MHz wall clock (s_memrealtime, one counter for the whole chip): when the waves START (the dispatcher's
     # ramp) against how long one of them lives -- a one-generation launch is the sum of the two, not a throughput

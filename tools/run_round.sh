@@ -31,7 +31,10 @@ profiles)
     echo; echo "# the same kernels with L2-resident loads and no stores (ntt_plan_set_debug(3)): the VALU floor"; python3 tools/sq_table.py $(find gpurun_out/sq_floor -name '*counter_collection.csv' | head -1); } > $S/${TAG}_sq_real_vs_floor.txt
   cat $S/${TAG}_sq_real_vs_floor.txt
   rm -rf gpurun_out/sq_real gpurun_out/sq_floor
-  # where the cycles of the two headline kernels go (diagnostic side build with s_memtime stamps, built HERE: tools/ab_build.sh stamps -DNTT_PHASE_STAMPS)
+  # where the cycles of the two headline kernels go (diagnostic side build with s_memtime stamps; git-ignored, so built right here
+  # unless it travelled with the snapshot; a failed build is SAID, never silently skipped)
+  [ -f ab/libntt_stamps.so ] || bash tools/ab_build.sh stamps -DNTT_PHASE_STAMPS > gpurun_out/build_stamps.log 2>&1 || true
+  if [ ! -f ab/libntt_stamps.so ]; then echo "SKIPPED: phase stamps (ab/libntt_stamps.so failed to build: gpurun_out/build_stamps.log)"; fi
   if [ -f ab/libntt_stamps.so ]; then
     mkdir -p $S/trace
     timeout -k 10 300 python3 tools/phase_stamps.py --trace-prefix $S/trace/trace_mi355x_n16 --trace-cycles 150000 > $S/${TAG}_phase_stamps.json 2> gpurun_out/stamps.err || tail -3 gpurun_out/stamps.err
@@ -39,8 +42,15 @@ profiles)
   fi
   # the vector ALU's throughput per instruction form: the price list of tools/hw.py (tools/valu_peak.hip, built HERE)
   if [ -x tools/valu_peak ]; then timeout -k 10 200 tools/valu_peak > $S/${TAG}_valu_peak.txt 2>&1 || true; fi
-  # the butterfly statement against occupancy, 1 .. 8 waves per SIMD (tools/stream_occupancy.hip, built HERE)
-  if [ -x tools/stream_occupancy ]; then timeout -k 10 200 tools/stream_occupancy > $S/${TAG}_stream_occupancy.txt 2>&1 || true; fi
+  # the butterfly statement against occupancy, 1 .. 8 waves per SIMD (tools/stream_occupancy.hip; built right here, stamped with
+  # the hash of the generator + probe it was made from: bench.statement_steady_state quotes it only when that hash is the tree's)
+  if [ ! -x tools/stream_occupancy ]; then
+    { mkdir -p ab && NTT_GEN_W=1 python3 tools/gen_gl_asm.py ab/gl_asm_w.h && hipcc -O3 --offload-arch=gfx950 -I ab tools/stream_occupancy.hip -o tools/stream_occupancy; } > gpurun_out/build_stream_occupancy.log 2>&1 || true
+  fi
+  if [ -x tools/stream_occupancy ]; then
+    { echo "# stream_src_hash $(python3 -c 'import bench; print(bench.stream_source_hash())')"; timeout -k 10 200 tools/stream_occupancy; } > $S/${TAG}_stream_occupancy.txt 2>&1 || true
+  else echo "SKIPPED: stream occupancy table (tools/stream_occupancy failed to build: gpurun_out/build_stream_occupancy.log)"; fi
+  if [ ! -x tools/valu_peak ]; then echo "SKIPPED: valu_peak (tools/valu_peak absent: __graft_entry__.build() makes it)"; fi
   python3 tools/bench_configs.py > $S/${TAG}_bench_all_configs.jsonl 2> gpurun_out/cfg.err || true
   python3 tools/bench_m64.py > $S/${TAG}_bench_m64.jsonl 2>> gpurun_out/cfg.err || true
   NTT_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --single-process --no-cpu-baseline --no-valu-floor > $S/${TAG}_bench_single_process_rehearsal.json 2>> gpurun_out/cfg.err || true
