@@ -284,7 +284,7 @@ def statement_steady_state():
 
 
 def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, stream_counts=None, statement=None):
-    """The vector-ALU roofline of the forward transform on the unit's MEASURED throughput (tools/hw.py, profiles/r05_valu_peak.txt:
+    """The vector-ALU roofline of the forward transform on the unit's MEASURED throughput (tools/hw.py, profiles/r06_valu_peak.txt:
     4 cycles per wave64 instruction for the VOP3-class forms the butterfly statements are made of -- SGPR-pair carries, 64-bit compare,
     select by SGPR pair, v_mad_u64_u32 -- 2 cycles for plain moves and adds):
       peak cycles per butterfly = stream's VOP3-class instructions x 4 + its moves x 2 + (SQ_INSTS_VALU per butterfly - stream length) x 4
@@ -374,26 +374,36 @@ def sane_clocks(clocks):
 
 # ---- the printed line: numbers, not commentary (the reference prints numbers, src/test.cpp:171-174) -------------------------
 # Keys that explain other keys.  `--explain` keeps them (tools/design_table.py and the counter-provenance tests read them); the
-# default line drops them, cuts provenance strings to the file they name and rounds nested floats to 6 significant digits, so
+# default line drops them, cuts provenance strings to the file they name and rounds nested floats to 5 significant digits, so
 # that the driver-run line stays below 6 KB.  What every key means: DESIGN.md section 4 ("Reading the line").
 PROSE_KEYS = {"what", "definition", "bound_note", "frac_of_practical_hbm_what", "verdict", "data_note"}
-TOP_LEVEL_EXACT = {"value", "ms_per_step", "butterflies_per_s", "ops_per_s_reference_convention"}
+TOP_LEVEL_EXACT = {"value", "ms_per_step", "butterflies_per_s", "ops_per_s_reference_convention"}  # (the last two: 7 digits, below)
+
+
+# per extra configuration (out["configs"][i]) the slim line keeps the measurement and the verdicts; the shape's description is
+# tools/configs.py's (by `key`), the generator is the headline's
+CONFIG_DROP = {"name", "data", "logn", "word_bytes", "modulus", "batch", "op",  # the shape is tools/configs.py's, by `key`
+               "ms_back_to_back"}                                                 # == ms; every MEASURED key stays
+CONFIG_ROOFLINE_DROP = {"bound_detail", "roofline_of_fields"}  # (the numbers the detail is made of are keys of their own)
+CONFIG_VALU_DROP = {"kernels", "kernel_cycles", "held_clock_note"}
 
 
 def slim_line(out):
-    """the default line from the full one: no prose keys, short provenance, 6 significant digits below the top level"""
+    """the default line from the full one: no prose keys, short provenance, 5 significant digits below the top level"""
+    import re
+
     def short(k, v):
-        if k.endswith("_source") and isinstance(v, str):
+        if (k.endswith("_source") or k == "source") and isinstance(v, str):
             for cut in (";", " -- ", " ("):
                 v = v.split(cut)[0]
-            return v[:96]
+            return v[9:] if v.startswith("profiles/") else v[:96]  # a bare rNN_*.json / .txt is a file under profiles/
         if k == "kernels" and isinstance(v, list):  # a kernel's identity = its PassCfg<...> argument list (tools/kernel_key.py)
-            import re
-
             def ident(x):
                 m = re.search(r"PassCfg<([^<>]*)>", x)
-                return m.group(1) if m else x[:64]
+                return (m.group(1) if m else x[:64]).replace("ntt::", "").replace(" ", "")
             return [ident(x) if isinstance(x, str) else x for x in v]
+        if k == "statement_alone_steady_state" and isinstance(v, dict):
+            return {q: v[q] for q in ("cycles_per_butterfly_at_4_or_more_waves", "kernel_over_statement", "source") if q in v}
         return v
 
     def walk(o, top=False):
@@ -402,10 +412,41 @@ def slim_line(out):
         if isinstance(o, list):
             return [walk(v) for v in o]
         if isinstance(o, float):
-            return float("%.6g" % o)
+            v = float("%.5g" % o)
+            return int(v) if abs(v) >= 1e6 and v == int(v) else v  # (4295000000 instead of 4295000000.0)
         return o
 
-    return walk(out, top=True)
+    slim = walk(out, top=True)
+    for k in ("butterflies_per_s", "ops_per_s_reference_convention"):  # derived from `value`: 7 digits
+        if isinstance(slim.get(k), float):
+            slim[k] = float("%.7g" % slim[k])
+    for e in slim.get("configs") or []:
+        for k in CONFIG_DROP:
+            e.pop(k, None)
+        r = e.get("roofline") or {}
+        for k in CONFIG_ROOFLINE_DROP:
+            r.pop(k, None)
+        if isinstance(r.get("valu"), dict):
+            r["valu"] = {k: v for k, v in r["valu"].items() if k not in CONFIG_VALU_DROP}
+        if e.get("key") == "cfg5_shard" and "headline" in str((out.get("configs") or [{}] * 9)[slim["configs"].index(e)].get("roofline", {}).get("valu_source", "")):
+            # its counters are the HEADLINE's (the same two kernels at twice the rows, scaled): the numbers are in `roofline` above
+            r["valu"], r["valu_source"], r["traffic_source"] = None, "= roofline.valu (the headline's kernels)", "= roofline.traffic x rows / 4096"
+    h = slim.get("roofline") or {}
+    if isinstance(h.get("valu"), dict):
+        # strings and constants: the kernels' identities are the keys of the file valu_source names, the prices are tools/hw.py's,
+        # the statement's plain-instruction count is the generator's (22 VALU of which 2 moves)
+        for k in ("kernels", "held_clock_note", "peak_cycles_per_wave_instr", "peak_clock_GHz", "plain_instr_per_butterfly"):
+            h["valu"].pop(k, None)
+    for r in slim.get("ranks") or []:
+        if r.get("pci_bus_id"):  # one identity per rank is enough in the slim line
+            r.pop("uuid", None)
+            r.pop("name", None)
+    c = slim.get("cpu_baseline") or {}
+    for k in [k for k in c if k.startswith("sample_rows_wanted") or k in ("sample_capped_at_batch", "threads_all_cores_leg")]:
+        c.pop(k)
+    if isinstance(h.get("valu_floor_source"), str):
+        h["valu_floor_source"] = h["valu_floor_source"].split(":")[0]
+    return slim
 
 
 def emit(out, args):
@@ -608,7 +649,7 @@ def self_launch(args, argv):
 
 def config_name(logn, batch, world):
     if logn == 16 and batch == 4096:
-        return "BASELINE config 3, forward leg (the headline metric)" + (", weak-scaled" if world > 1 else "")
+        return "BASELINE config 3 forward leg (headline)" + (", weak-scaled" if world > 1 else "")
     if logn == 16 and batch == 8192:
         return "BASELINE config 5 (65536 rows over 8 GPUs = 8192 per GPU), %d GPU(s) here" % world
     return "off-headline shape (N=2^%d, %d per GPU)" % (logn, batch)
@@ -627,8 +668,8 @@ def base_line(args, logn, batch, world, value, elapsed, passes, table_broadcast,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": PREWARM,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic", "launch": launch,
-        "config": {"workload": "%s; forward NTT N=2^%d, p=2^64-2^32+1, table make_roots(g=7), batch %d per GPU (%d in the job), out of "
-                               "place, resident in HBM" % (config_name(logn, batch, world), logn, batch, batch * world),
+        "config": {"workload": "%s: forward NTT N=2^%d, Goldilocks, make_roots(g=7) table, batch %d/GPU (%d in the job), out of place, "
+                               "HBM-resident" % (config_name(logn, batch, world), logn, batch, batch * world),
                    "data_note": "a[b][i] = splitmix64(0x9E3779B97F4A7C15 + b*N + i) mod p (SURVEY 8d)",
                    "baseline_config": (3 if (logn == 16 and batch == 4096) else 5 if (logn == 16 and batch == 8192) else None),
                    "batch_per_gpu": batch, "hbm_passes": len(passes),

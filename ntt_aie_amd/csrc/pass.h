@@ -56,6 +56,9 @@
 #ifndef NTT_PPW_CAP_COL_INV
 #define NTT_PPW_CAP_COL_INV 4  // ... inverse Goldilocks column passes
 #endif
+#ifndef NTT_PREFETCH_M32_WIDE
+#define NTT_PREFETCH_M32_WIDE 1  // PassCfg::PREFETCH (0: round 5's kernels)
+#endif
 #ifndef NTT_PRODUCT_TW_EARLY
 #define NTT_PRODUCT_TW_EARLY 1  // product pass: read the next round's LDS-table twiddles before the exchange barrier (measured -0.5 .. -0.9 %)
 #endif
@@ -182,6 +185,13 @@ struct PassCfg {
     // which is where a fused pointwise product has room to multiply.
     static constexpr bool DMA = ALLOW_DMA_ && CONTIG && !INV && R > 1 && LOG_E_ < 4 && sizeof(W) == 8;
     static constexpr int LDS_WORDS = LDS_WORDS_PADDED;
+    // Register prefetch of the NEXT polynomial's tile (round 6, BASELINE config 2): the 4-byte 512-thread radix-8 kernels that run a
+    // single-pass size (PassDesc::variant 1) stage their tile linearly by ordinary loads; with PREFETCH a thread requests its E words
+    // of polynomial it + 1 into a second register set (E VGPRs of 4-byte words) right after round 0 of polynomial `it` has its words,
+    // and commits them to LDS at the start of the next iteration -- the HBM latency of every polynomial but the first hides under
+    // the previous one's butterflies, so a launch can stream TWO polynomials per workgroup through ONE generation of workgroups
+    // (pass_geometry: one_generation_wgs) instead of leaving a quarter of them to a second generation.
+    static constexpr bool PREFETCH = NTT_PREFETCH_M32_WIDE && ALLOW_DMA_ && CONTIG && !INV && R > 1 && LOG_E_ < 4 && LOG_NT_ == 9 && sizeof(W) == 4;
     // Most polynomials a workgroup streams through its resident twiddles (tools/ppw_sweep.py, N = 2^13 .. 2^17, batches
     // 2048 .. 16384): the 256-thread Goldilocks LDS-DMA first passes are fastest at 8 whatever the batch (16 costs 5-6 % at
     // batch 8192), the Goldilocks column passes at 4 (8 costs 4 %); the other kernels keep the workgroup-count rule alone.
@@ -282,6 +292,7 @@ template <class Cfg>
 struct Ctx {
     using W = typename Cfg::W;
     W x[Cfg::E];
+    W pre[Cfg::PREFETCH ? Cfg::E : 1];  // PassCfg::PREFETCH: the next polynomial's linear chunks, in flight during this one's rounds
     W tw[Cfg::R][Cfg::E > 1 ? Cfg::E - 1 : 1];
     uint32_t tid, bx, by;
     uint32_t pg_base;        // first polynomial group of this workgroup
@@ -707,10 +718,34 @@ using u32x4_t = unsigned int __attribute__((ext_vector_type(4)));
 // staging set: chunk i in x[i*V .. i*V+V)); with a fused pointwise product (a.in2, the negacyclic product's middle leg)
 // the second operand's chunks follow and the products replace the staged words.
 template <class Cfg>
-NTT_HD void phase_linear_issue(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
+NTT_HD void phase_linear_issue(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it, bool to_pre = false) {
     using G = LinearGeom<Cfg>;
     using Ch = typename G::Ch;
     const G g(c, a, it);
+    if constexpr (Cfg::PREFETCH) {
+        if (to_pre) {  // the same chunks into the prefetch registers (plain transforms only: the launcher never pairs in2 with these kernels)
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t voff = (g.wbase + g.lane) * (uint32_t) sizeof(typename Cfg::W);
+            const __amdgpu_buffer_rsrc_t rs = linear_rsrc<Cfg>(a.in, a, g.tile0);
+#pragma unroll
+            for (int i = 0; i < G::ITER; ++i) {
+                const u32x4_t d = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (uint32_t) i * G::STEP * (uint32_t) sizeof(typename Cfg::W), Cfg::LIN_AUX);
+                Ch v;
+                __builtin_memcpy(&v, &d, 16);
+#pragma unroll
+                for (int k = 0; k < G::V; ++k) c.pre[i * G::V + k] = v.v[k];
+            }
+#else
+            for (int i = 0; i < G::ITER; ++i) {
+                Ch v;
+                for (int k = 0; k < G::V; ++k) v.v[k] = 0;
+                if (g.active(a, i)) v = *reinterpret_cast<const Ch *>(a.in + g.tile0 + g.lin(i));
+                for (int k = 0; k < G::V; ++k) c.pre[i * G::V + k] = v.v[k];
+            }
+#endif
+            return;
+        }
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(sizeof(Ch) == 16, "linear tiles move 16-byte chunks");
     const uint32_t voff = (g.wbase + g.lane) * (uint32_t) sizeof(typename Cfg::W);
@@ -758,15 +793,16 @@ NTT_HD void phase_linear_issue(Ctx<Cfg> &c, const PassArgs<Cfg> &a, int it) {
 
 // registers -> LDS (the wave's own segment of the tile)
 template <class Cfg>
-NTT_HD void phase_linear_commit(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *lds, int it) {
+NTT_HD void phase_linear_commit(Ctx<Cfg> &c, const PassArgs<Cfg> &a, typename Cfg::W *lds, int it, bool from_pre = false) {
     using G = LinearGeom<Cfg>;
     using Ch = typename G::Ch;
     const G g(c, a, it);
+    const typename Cfg::W *src = (Cfg::PREFETCH && from_pre) ? c.pre : c.x;
 #pragma unroll
     for (int i = 0; i < G::ITER; ++i) {
         Ch v;
 #pragma unroll
-        for (int k = 0; k < G::V; ++k) v.v[k] = c.x[i * G::V + k];
+        for (int k = 0; k < G::V; ++k) v.v[k] = src[i * G::V + k];
         for (int k = 0; k < G::V; ++k) NTT_LDS_ACCESS(lds + g.lds(i) + k, c.tid, true);
         *reinterpret_cast<Ch *>(lds + g.lds(i)) = v;
     }
@@ -1184,12 +1220,20 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
             ex.each([&](C &c) { phase_load_direct<Cfg, FIRST>(c, a, it); });
             prio_down();
         } else {
-            if (!EARLY_LOAD || it > 0) ex.each([&](C &c) { phase_linear_issue<Cfg>(c, a, it); });
-            ex.each([&](C &c) { phase_linear_commit<Cfg>(c, a, tile, it); });
+            const bool prefetched = Cfg::PREFETCH && it > 0;  // (uniform) this tile's chunks were requested during the previous iteration
+            if (!prefetched && (!EARLY_LOAD || it > 0)) ex.each([&](C &c) { phase_linear_issue<Cfg>(c, a, it); });
+            ex.each([&](C &c) { phase_linear_commit<Cfg>(c, a, tile, it, prefetched); });
             // round 0 of thread t reads words [E*t, E*t + E) of the tile: the segment its own wave has just staged, so this
             // hand-off is wave-local whatever the unit size (as with the LDS-DMA tiles); the later exchanges keep their barrier
             ex.sync(std::integral_constant<bool, FIRST == 0 || Cfg::WAVE_LOCAL>{});  // (an inverse pass staged this way is a small, wave-local unit)
             ex.each([&](C &c) { phase_lds_read<Cfg, FIRST>(c, tile, Cfg::INV && block16_here<Cfg>(a)); });
+            if constexpr (Cfg::PREFETCH) {  // the next polynomial's chunks travel while this one's rounds run
+                if (group_valid(it + 1)) {
+                    prio_up();
+                    ex.each([&](C &c) { phase_linear_issue<Cfg>(c, a, it + 1, true); });
+                    prio_down();
+                }
+            }
         }
         stamp(ex, sb + 2);  // (the diagnostic build's stamp waits for the words: s_waitcnt vmcnt / lgkmcnt, see GpuExec::stamp)
         static_for<0, R>([&](auto kk) {

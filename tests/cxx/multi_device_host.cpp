@@ -43,6 +43,26 @@ int main(int argc, char **argv) {
     const size_t S = dev.size();
     std::printf("devices: %d, shards: %zu, N = 2^%d, batch %zu\n", ndev, S, logn, B);
 
+    // First contact with a multi-GPU node must be readable: ntt_plan_clone copies the tables with
+    // hipMemcpyPeer, which the runtime serves over xGMI when the two devices can access each other and SILENTLY stages through
+    // host memory when they cannot.  Say which one every device pair is -- loudly, before anything runs -- and count them.
+    int direct = 0, staged = 0;
+    for (size_t s = 1; s < S; s++) {
+        if (dev[s] == dev[0]) continue;  // same-device replica: an ordinary device-to-device copy
+        int can = 0;
+        CHECK_HIP(hipDeviceCanAccessPeer(&can, dev[s], dev[0]));
+        if (can) {
+            ++direct;
+        } else {
+            ++staged;
+            std::printf("  WARNING: device %d cannot access device %d directly: the table copy of this clone is STAGED THROUGH THE HOST "
+                        "(hipMemcpyPeer's fallback), not sent over xGMI\n", dev[s], dev[0]);
+        }
+    }
+    std::printf("peer table copies: %d direct (xGMI), %d staged through the host, %zu on the source device\n", direct, staged,
+                S - 1 - (size_t) direct - (size_t) staged);
+    if (staged && std::getenv("NTT_MD_REQUIRE_PEER")) { std::printf("  FAIL. (NTT_MD_REQUIRE_PEER: a staged copy is an error)\n"); return 1; }
+
     // ONE plan with a device-generated table (no host table exists anywhere), cloned onto every other shard's device
     std::vector<ntt_plan_t> plan(S, nullptr);
     CHECK_NTT(ntt_plan_create(&plan[0], logn, p, 8, dev[0]));

@@ -105,7 +105,7 @@ def test_verdict_fields_single_rank():
 
 
 def test_valu_roofline_arithmetic_on_a_synthetic_mix():
-    """roofline.valu on the unit's MEASURED throughput (tools/hw.py, profiles/r05_valu_peak.txt: 4 cycles per wave64 instruction for
+    """roofline.valu on the unit's MEASURED throughput (tools/hw.py, profiles/r06_valu_peak.txt: 4 cycles per wave64 instruction for
     the VOP3-class forms of the butterfly statements, 2 for plain moves / adds): the forward statement's 22 VALU (20 + 2 moves) cost
     84 cycles at peak, the counter's extra instructions 4 each; at 103.0 / 104.9 kernel cycles per wave-butterfly per SIMD that is
     0.86 / 0.81 -- rounds 1-4's flat 4-cycle price said 0.91, round 5's first re-base on the guide's 2 cycles said 0.45."""
@@ -312,7 +312,8 @@ def test_sane_clocks_and_time_weighted_bound():
 
 def test_slim_line_drops_prose_keeps_numbers():
     """bench.slim_line: the default line has no explanatory keys, provenance strings are cut to the file they name, nested floats
-    carry 6 significant digits, and the contract's top-level numbers are untouched."""
+    carry 5 significant digits, the extra configurations keep their measurements (their shapes are tools/configs.py's, by key), and
+    the contract's top-level numbers are untouched."""
     import json
 
     import bench
@@ -325,15 +326,16 @@ def test_slim_line_drops_prose_keeps_numbers():
                          "traffic_source": "profiles/r05_pmc_traffic.json (src_hash abc); forward kernels: " + "k" * 200,
                          "valu": {"what": "v" * 600, "held_clock_GHz": [1.93, None],
                                   "kernels": ["void ntt::(anonymous namespace)::pass_kernel<ntt::PassCfg<ntt::FieldGL, 8, 0, true, false, 15, 3, 8, true>, false>(ntt::PassArgs<...>)"]}},
-            "configs": [{"name": "c", "roofline": {"definition": "d" * 100, "frac": 0.29912345678}}]}
+            "configs": [{"name": "c", "key": "cfg2", "ms": 0.014, "roofline": {"definition": "d" * 100, "bound_detail": "b" * 100, "frac": 0.29912345678}}]}
     slim = bench.slim_line(full)
     text = json.dumps(slim)
     assert slim["value"] == full["value"] and slim["ms_per_step"] == full["ms_per_step"]
     assert "what" not in slim["verification"] and "bound_note" not in slim["roofline"] and "definition" not in slim["roofline"]
     assert "definition" not in slim["configs"][0]["roofline"] and "what" not in slim["roofline"]["valu"] and "data_note" not in slim["config"]
-    assert slim["roofline"]["frac"] == 0.323674 and slim["roofline"]["pass_ms"] == [0.830123, 0.817123] and slim["configs"][0]["roofline"]["frac"] == 0.299123
-    assert slim["roofline"]["traffic_source"] == "profiles/r05_pmc_traffic.json" and slim["roofline"]["bound_detail"] == "short"
-    assert slim["roofline"]["valu"]["kernels"] == ["ntt::FieldGL, 8, 0, true, false, 15, 3, 8, true"] and slim["roofline"]["valu"]["held_clock_GHz"] == [1.93, None]
+    assert slim["roofline"]["frac"] == 0.32367 and slim["roofline"]["pass_ms"] == [0.83012, 0.81712] and slim["configs"][0]["roofline"]["frac"] == 0.29912
+    assert slim["roofline"]["traffic_source"] == "r05_pmc_traffic.json" and slim["roofline"]["bound_detail"] == "short"  # (a file under profiles/)
+    assert "kernels" not in slim["roofline"]["valu"] and slim["roofline"]["valu"]["held_clock_GHz"] == [1.93, None]
+    assert "name" not in slim["configs"][0] and "bound_detail" not in slim["configs"][0]["roofline"]
     assert len(text) < 900 and full["roofline"]["bound_note"] == "y" * 500  # the input is not modified
 
 

@@ -352,7 +352,7 @@ def test_bench_json_contract():
     # the run's own numbers (bench.decide_bound: a roofline is named only at >= 0.9 of it), frac_ceiling is what frac can reach
     # with this pass count
     assert r["bound"] in ("hbm", "valu", "power-cap", "unsaturated") and r["roofline_of_fields"] == "hbm" and r["bound_detail"]
-    assert r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 * r["frac"]  # (the default line rounds nested floats to 6 digits)
+    assert r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 * r["frac"]  # (the default line rounds nested floats to 5 digits)
     assert "configs" not in d  # the extra configurations ride on the default shape only (batch 4096)
     assert r["frac_ceiling"] == pytest.approx(1.0 / r["passes"]) and r["frac"] <= r["frac_ceiling"]
     assert "valu" in r and "valu_source" in r and "inverse" in d and d["inverse"]["round_trip_identical"] is True

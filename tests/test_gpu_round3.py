@@ -260,6 +260,7 @@ def test_cxx_multi_device_host(tmp_path):
     for env_extra, shards in (({}, None), ({"NTT_MD_REPLICAS": "2"}, 3)):
         out = subprocess.run([exe, "16", "37"], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env_extra))
         assert out.returncode == 0 and "PASS!" in out.stdout and "MISMATCH" not in out.stdout, out.stdout + out.stderr
+        assert "peer table copies: 0 direct (xGMI), 0 staged through the host" in out.stdout  # one device: nothing crosses a link, and the line says so
         if shards:
             assert "shards: %d" % shards in out.stdout and out.stdout.count(" ok") == shards
 

@@ -318,13 +318,13 @@ def test_bench_json_contract_frac_step_and_gpu_input_sample():
     r = d["roofline"]
     assert "frac_step_uncapped" not in r and 0 < r["frac_step"] <= r["frac"] * 1.08 and r["frac"] <= r["frac_ceiling"]
     assert abs(r["frac_step"] / r["frac"] - 1) < 0.15  # step time and summed kernel time describe the same launches (5 steps: the clock the chip holds in each phase moves them a few per cent apart)
-    assert abs(r["achieved_step"] - r["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9) / r["achieved_step"] < 1e-5  # (6 digits)
+    assert abs(r["achieved_step"] - r["algorithmic_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9) / r["achieved_step"] < 1e-4  # (nested floats carry 5 digits)
     # the step against what two trips at this run's device-copy rate would take: a fraction of a floor, so below 1 up to clock noise
-    assert 0.5 < r["frac_of_practical_hbm"] < 1.05 and abs(r["practical_hbm_floor_ms"] - 2 * r["device_copy"]["ms"]) < 1e-5 * r["practical_hbm_floor_ms"]
+    assert 0.5 < r["frac_of_practical_hbm"] < 1.05 and abs(r["practical_hbm_floor_ms"] - 2 * r["device_copy"]["ms"]) < 1e-4 * r["practical_hbm_floor_ms"]
     assert r["bound"] in ("hbm", "valu", "power-cap", "unsaturated") and r["roofline_of_fields"] == "hbm" and r["bound_detail"]
     if r["valu"] is not None:  # counters of exactly these sources are committed: the vector ALU against its MEASURED throughput (tools/hw.py)
         v = r["valu"]
-        assert v["peak_cycles_per_wave_instr"]["vop3_class"] == 4.0 and v["peak_cycles_per_wave_instr"]["plain_moves_adds"] == 2.0
+        assert "peak_cycles_per_wave_instr" not in v  # constants (tools/hw.py) are not repeated in the slim line; --explain has them
         assert 0.5 < v["frac_of_peak_at_held_clock"] < 1.0 and all(80 < c < 95 for c in v["peak_cycles_per_butterfly"])
         assert all(0 < f < 1.0 for f in v["frac_of_peak_at_held_clock_per_pass"])
         assert (r["bound"] == "valu") == (v["frac_of_peak_at_held_clock"] >= 0.95 and min(r["pass_stream_frac_of_device_copy"]) < 0.95)
@@ -336,16 +336,16 @@ def test_bench_json_contract_frac_step_and_gpu_input_sample():
     # configs 2 and 4, driver-observed: one entry each, verified, with the roofline keys of the headline
     assert [e["key"] for e in d["configs"]] == ["cfg2", "cfg4", "cfg5_shard"] and d["configs_all_verified"] is True
     c2, c4, c5 = d["configs"]
-    assert c5["baseline_config"] == 5 and c5["batch"] == 8192 and c5["verified"] and c5["hbm_passes"] == 2 and c5["unit"] == "NTT/s"
+    assert c5["baseline_config"] == 5 and c5["key"] == "cfg5_shard" and "batch" not in c5 and c5["verified"] and c5["hbm_passes"] == 2 and c5["unit"] == "NTT/s"
     assert 0.5 * d["value"] < c5["value"] < 1.5 * d["value"]  # the shard runs at the headline's rate (twice the rows, twice the time)
     assert c2["baseline_config"] == 2 and c2["verified"] and c2["verification"]["round_trip_identical"] and c2["verification"]["coefficient_sum_invariant"]
-    assert c2["unit"] == "NTT/s" and 0 < c2["ms"] < 1.0 and abs(c2["value"] - 1024 / (c2["ms"] * 1e-3)) / c2["value"] < 1e-5
+    assert c2["unit"] == "NTT/s" and 0 < c2["ms"] < 1.0 and abs(c2["value"] - 1024 / (c2["ms"] * 1e-3)) / c2["value"] < 1e-4
     assert c4["baseline_config"] == 4 and c4["verified"] and c4["verification"]["evaluation_at_root_of_xN_plus_1"] and c4["verification"]["transform_domain_identity_whole_batch"]
     assert c4["unit"] == "products/s" and 1.0 < c4["ms"] < 100.0
     for e in (c2, c4, c5):
         rr = e["roofline"]
         assert 0 < rr["frac"] <= rr["frac_ceiling"] <= 1.0 and rr["peak"] == 8000.0 and rr["unit"] == "GB/s" and rr["bound"]
-        assert abs(rr["achieved"] - rr["algorithmic_bytes_per_op"] / (e["ms"] * 1e-3) / 1e9) / rr["achieved"] < 1e-5
+        assert abs(rr["achieved"] - rr["algorithmic_bytes_per_op"] / (e["ms"] * 1e-3) / 1e9) / rr["achieved"] < 1e-4
 
 
 # ---- the wide radix-8 variant of the 4-byte single-pass sizes (plan.h: PassDesc::variant 1) ---------------------------------

@@ -37,9 +37,14 @@ def test_valu_price_list_is_what_this_gpu_measures():
     tflops_at_peak_clock = 4 * 64 / pk["cycles"] * hw.PEAK_CLOCK_GHZ * 1e9 * hw.SIMDS / 1e12
     assert 0.92 * 157.3 < tflops_at_peak_clock < 1.05 * 157.3, (pk, tflops_at_peak_clock)
     assert 1.0 < rows["v_mov_b32"]["ghz"] < 2.6  # the in-kernel clock the cycles are computed with is a sane shader clock
-    # round 6: the rows that reconcile v_fma_f32's 3.3 cycles with the guide's 2: whatever they come out at, the
-    # two-source forms cannot be SLOWER than the three-source one, and the VOP2 carry forms are priced like the SGPR-pair ones or cheaper
-    for name in ("v_fmac_f32", "v_fma_f32_2src", "v_mul_f32", "v_add_co_u32_e32", "v_addc_co_u32_e32"):
-        assert name in rows and 1.5 < rows[name]["cycles"] < 4.6, (name, rows.get(name))
-    assert rows["v_fmac_f32"]["cycles"] <= rows["v_fma_f32"]["cycles"] * 1.05
-    assert rows["v_add_co_u32_e32"]["cycles"] <= rows["v_add_co_u32"]["cycles"] * 1.05
+    # round 6: the rows that were to reconcile v_fma_f32's 3.3 cycles with the guide's 2.  They do not: the VOP2
+    # two-source forms (v_fmac_f32, v_mul_f32) cost what the three-source VOP3 form costs, so the 3.3 is not an operand-port effect of
+    # the probe -- the guide's 2-cycle row is not reproducible with this method on this part.  Asserted here: the
+    # f32 forms sit together between the plain moves (2) and the VOP3-class integer forms (4), and the VOP2 carry forms are priced
+    # like the SGPR-pair ones (the statements' prices do not depend on which carry register a form names).
+    for name in ("v_fma_f32", "v_fmac_f32", "v_fma_f32_2src", "v_mul_f32"):
+        assert name in rows and 2.0 < rows[name]["cycles"] < 4.3, (name, rows.get(name))
+    f32 = [rows[k]["cycles"] for k in ("v_fma_f32", "v_fmac_f32", "v_fma_f32_2src")]
+    assert max(f32) / min(f32) < 1.35, f32
+    for name in ("v_add_co_u32_e32", "v_addc_co_u32_e32"):
+        assert name in rows and 1.8 < rows[name]["cycles"] < 1.10 * hw.VALU_PEAK_CYCLES_VOP3, (name, rows.get(name))

@@ -3,12 +3,15 @@ summary / plot tools, so that no two files can state different peaks.
 
 HBM3E ~8 TB/s, 256 CUs x 4 SIMDs, peak engine clock 2.4 GHz: /opt/skills/guides/MI355X_MICROARCH.md (spec table).
 
-Vector-ALU throughput per wave64 instruction: MEASURED, profiles/r05_valu_peak.txt (tools/valu_peak.hip: launches of 12
+Vector-ALU throughput per wave64 instruction: MEASURED, profiles/r06_valu_peak.txt (r05's rows reproduced; tools/valu_peak.hip: launches of 12
 generations of workgroups, cycles = launch duration x in-kernel clock / wave-instructions per SIMD -- no assumption about how many
 waves are resident):
     v_add_co_u32 / v_addc_co_u32 (SGPR-pair carries), v_mad_u64_u32, v_mul_lo_u32, v_cndmask_b32 by SGPR pair   4.04 - 4.08 cycles
     v_mov_b32, v_add_u32                                                                                         2.09 - 2.15 cycles
-    v_pk_fma_f32  4.06 cycles = 154 TFLOP/s at 2.4 GHz (the data sheet's 157.3: the method reproduces it)        v_fma_f32  3.3 cycles
+    v_pk_fma_f32  4.06 cycles = 154 TFLOP/s at 2.4 GHz (the data sheet's 157.3: the method reproduces it)
+    v_mul_f32 (VOP2, two operands) 2.09 -- the guide's 2-cycle rate; every FMA form 3.3 - 3.45 (v_fma_f32 with three or two different
+    sources, v_fmac_f32): the third operand read costs, whatever the encoding (round 6; MI355X_MICROARCH.md's "v_fma_f32: 2" could not be
+    reproduced with this method); the VOP2 carry forms through VCC 4.05 - 4.06, like the SGPR-pair ones
 Nominal prices below: 4 cycles (16 lanes per clock) for the VOP3-class forms the butterfly streams are made of, 2 cycles (32 lanes
 per clock) for plain VOP1 / VOP2 moves and adds.
 
@@ -25,7 +28,7 @@ SIMDS = CUS * 4
 PEAK_CLOCK_GHZ = 2.4
 VALU_PEAK_CYCLES_VOP3 = 4.0   # carry forms, 64-bit compare, select by SGPR pair, v_mul_lo/hi_u32, v_mad_u64_u32, v_lshl_add_u64
 VALU_PEAK_CYCLES_PLAIN = 2.0  # v_mov_b32, v_add_u32, v_sub_u32, v_and_b32, v_or_b32, v_xor_b32 (VOP1 / VOP2, no carry)
-VALU_PEAK_SOURCE = "profiles/r05_valu_peak.txt (tools/valu_peak.hip: steady-state throughput, launch duration x clock / wave-instructions)"
+VALU_PEAK_SOURCE = "profiles/r06_valu_peak.txt (tools/valu_peak.hip: steady-state throughput, launch duration x clock / wave-instructions)"
 # the reference's efficiency convention divides "operations" (5.5 N log2 N per transform, profile/plot_efficiency.py:25,44) by a
 # peak in GOPS (A100 4280, AIE 88: plot_efficiency.py:27,46); MI355X on the same footing: the rate of its FASTEST 32-bit integer
 # vector instructions (plain adds: 32 lanes per clock) -- a peak no instruction mix can exceed: 1024 SIMDs x 32 x 2.4 GHz
