@@ -41,7 +41,7 @@ from hw import (HBM_PEAK_GBS, PEAK_CLOCK_GHZ, SIMDS, VALU_PEAK_CYCLES_PLAIN, VAL
                 valu_frac_of_peak, valu_peak_cycles)  # tools/hw.py: the one place the peaks live
 
 SEED = 0x9E3779B97F4A7C15  # a[b][i] = splitmix64(SEED + b*N + i) mod p
-PROFILE_ROUND = "r05"  # the collection DESIGN.md section 4 is generated from (tools/design_table.py); counters are quoted from the newest matching round (tagged_profile)
+PROFILE_ROUND = "r06"  # the collection DESIGN.md section 4 is generated from (tools/design_table.py); counters are quoted from the newest matching round (tagged_profile)
 
 
 def _s64(v: int) -> int:

@@ -66,4 +66,7 @@ collect_config cfg4 10 3
 cd /tmp
 python3 $ROOT/bench.py --explain > "$SUM/${TAG}_bench.json"   # the full line (explanatory keys kept: tools/design_table.py reads them); the driver runs the slim default
 tail -c 300 "$SUM/${TAG}_bench.json"; echo
+# ... and the line exactly as the driver gets it (no flags: numbers only, < 6 KB)
+python3 $ROOT/bench.py > "$SUM/${TAG}_bench_driver_line.json"
+wc -c "$SUM/${TAG}_bench_driver_line.json"
 ls -la "$SUM"

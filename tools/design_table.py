@@ -50,8 +50,14 @@ def headline(spread):
     pc, _ = power("copy (xor kernel)", pp)
     cb = d["cpu_baseline"]
     sa = v.get("statement_alone_steady_state") or {}
-    vp = [l.split() for l in open(P("%s_valu_peak.txt" % R)) if l[:2] == "v_"]
-    vpk = {l[0]: float(l[-1]) if l[0] not in ("v_pk_fma_f32", "v_fma_f32") else float(l[-2]) for l in vp}
+    if not sa:  # the line was printed before the round's stream-occupancy table was in profiles/: the same figures from the file itself
+        st = bench.statement_steady_state()
+        rows = {str(k): x for k, x in st["cycles_per_butterfly_by_waves_per_simd"].items()}
+        best = min(x for k, x in rows.items() if int(k) >= 4)
+        sa = {"cycles_per_butterfly_by_waves_per_simd": rows, "cycles_per_butterfly_at_4_or_more_waves": best,
+              "kernel_over_statement": [k / best for k in v["kernel_cycles_per_wave_butterfly_per_simd"]]}
+    # a 72-character label, then: ns, clock GHz, cycles[, TFLOP/s]
+    vpk = {l.split()[0]: float(l[72:].split()[2]) for l in open(P("%s_valu_peak.txt" % R)) if l[:2] == "v_"}
     rk = d["ranks"][0]
     ps = json.load(open(P("%s_phase_stamps.json" % R)))
     sp = [p["split"] for p in ps["passes"]]
@@ -68,7 +74,7 @@ def headline(spread):
 | `frac_of_practical_hbm` | two trips at the same-run device-copy rate ({cp:.2f} TB/s) would take {pf:.3f} ms: the step is at **{fp:.2f}** of that |
 | `roofline.traffic` (PMC, forward kernels) | {tr:.3f} GB = {trr:.2f} × algorithmic: two trips, no over-fetch within a pass |
 | each pass's stream rate | {s0:.2f} / {s1:.2f} TB/s = {f0:.2f}–{f1:.2f} of peak = {c0:.2f}–{c1:.2f} of the same-process device copy |
-| the vector ALU's **measured** throughput (`{R}_valu_peak.txt`, `tools/valu_peak.hip`: launch duration × in-kernel clock ÷ wave-instructions per SIMD, 12 generations of workgroups) | `v_add_co_u32` {vadd:.2f}, `v_addc_co_u32` {vaddc:.2f}, `v_mad_u64_u32` {vmad:.2f}, `v_mul_lo_u32` {vmul:.2f}, `v_cndmask_b32` by SGPR pair {vcnd:.2f} cycles per wave64 instruction; `v_mov_b32` {vmov:.2f}, `v_add_u32` {vaddu:.2f}; sanity: `v_pk_fma_f32` {vpk:.2f} cycles = the data sheet's 157 TFLOP/s at 2.4 GHz. Nominal prices (`tools/hw.py`): **4 cycles** for the statements' VOP3-class forms, **2** for plain moves / adds |
+| the vector ALU's **measured** throughput (`{R}_valu_peak.txt`, `tools/valu_peak.hip`: launch duration × in-kernel clock ÷ wave-instructions per SIMD, 12 generations of workgroups) | `v_add_co_u32` {vadd:.2f}, `v_addc_co_u32` {vaddc:.2f}, `v_mad_u64_u32` {vmad:.2f}, `v_mul_lo_u32` {vmul:.2f}, `v_cndmask_b32` by SGPR pair {vcnd:.2f} cycles per wave64 instruction; `v_mov_b32` {vmov:.2f}, `v_add_u32` {vaddu:.2f}; sanity: `v_pk_fma_f32` {vpk:.2f} cycles = the data sheet's 157 TFLOP/s at 2.4 GHz; `v_mul_f32` {vmulf:.2f} (the guide's two-operand rate), every FMA form {vfma:.2f}–{vfmac:.2f} (round 6: three operand reads cost that whatever the encoding). Nominal prices (`tools/hw.py`): **4 cycles** for the statements' VOP3-class forms, **2** for plain moves / adds |
 | `roofline.valu` on that throughput | {ipb:.2f} VALU per butterfly ({i0:.2f} / {i1:.2f}, 2 of them moves) = {pc0:.1f} / {pc1:.1f} cycles at peak; the kernels take {kc0:.1f} / {kc1:.1f} cycles per wave-butterfly per SIMD ({h0:.2f}–{h1:.2f} GHz under the counter run, {w0:.1f} / {w1:.1f} waves per SIMD): `frac_of_peak_at_held_clock` **{fh0:.2f} / {fh1:.2f}**; peak {pk:.2f}e12 bf/s at 2.4 GHz, {f24:.2f} of it in wall-clock terms |
 | … and the butterfly statement ALONE in steady state (`{R}_stream_occupancy.txt`, last table) | {st1:.0f} / {st2:.0f} / {st3:.0f} / {st4:.0f} / {st8:.0f} cycles per butterfly per SIMD at 1 / 2 / 3 / 4 / 8 resident waves: from four waves on it runs AT the unit's throughput ({stb:.0f} against 84 at nominal prices); the kernels take {ks0:.2f} / {ks1:.2f} × that |
 | **`roofline.bound` = `{bound}`** (decided by `bench.decide_bound` from these numbers) | {bd} |
@@ -90,7 +96,8 @@ def headline(spread):
            kc0=v["kernel_cycles_per_wave_butterfly_per_simd"][0], kc1=v["kernel_cycles_per_wave_butterfly_per_simd"][1],
            h0=min(v["held_clock_GHz"]), h1=max(v["held_clock_GHz"]), w0=v["mean_waves_per_simd"][0], w1=v["mean_waves_per_simd"][1],
            vadd=vpk["v_add_co_u32"], vaddc=vpk["v_addc_co_u32"], vmad=vpk["v_mad_u64_u32"], vmul=vpk["v_mul_lo_u32"], vcnd=vpk["v_cndmask_b32"],
-           vmov=vpk["v_mov_b32"], vaddu=vpk["v_add_u32"], vpk=vpk["v_pk_fma_f32"],
+           vmov=vpk["v_mov_b32"], vaddu=vpk["v_add_u32"], vpk=vpk["v_pk_fma_f32"], vmulf=vpk["v_mul_f32"],
+           vfma=min(vpk["v_fma_f32"], vpk["v_fma_f32_2src"], vpk["v_fmac_f32"]), vfmac=max(vpk["v_fma_f32"], vpk["v_fma_f32_2src"], vpk["v_fmac_f32"]),
            pc0=v["peak_cycles_per_butterfly"][0], pc1=v["peak_cycles_per_butterfly"][1],
            st1=sa["cycles_per_butterfly_by_waves_per_simd"]["1"], st2=sa["cycles_per_butterfly_by_waves_per_simd"]["2"],
            st3=sa["cycles_per_butterfly_by_waves_per_simd"]["3"], st4=sa["cycles_per_butterfly_by_waves_per_simd"]["4"],
@@ -116,11 +123,11 @@ def configs():
     def row(name, t, r, verified):
         v = r.get("valu") or {}
         wav = " / ".join("%.1f" % w for w in (v.get("mean_waves_per_simd") or []) if w)
-        clk = " / ".join("%.2f" % h for h in (v.get("held_clock_GHz") or []) if h and h < 2.6)
+        clk = " / ".join("%.2f" % h for h in (v.get("held_clock_GHz") or []) if h)  # (impossible quotients are nulled at the source: bench.sane_clocks)
         return "| %s | %s | %.3f (%.2f) | %s | %s | %s | **%s**: %s | %s |" % (
             name, ("%.1f µs" % (t * 1e3)) if t < 0.1 else ("%.3f ms" % t), r["frac"], r["frac_ceiling"],
             ("%.3f GB (%.3f)" % (r["traffic"] / 1e9, r["traffic_ratio_to_algorithmic"])) if r.get("traffic") else "not quoted",
-            ("%.2f; %.2f" % (v["instr_per_butterfly"], v["frac_of_peak_at_held_clock"])) if v else "not quoted",
+            ("%.2f; %s" % (v["instr_per_butterfly"], ("%.2f" % v["frac_of_peak_at_held_clock"]) if v.get("frac_of_peak_at_held_clock") else "n/a")) if v else "not quoted",
             ("%s; %s GHz" % (wav, clk or "n/a (launch too short for the counter quotient)")) if v else "—", r["bound"], r["bound_detail"], verified)
 
     def ver(e):

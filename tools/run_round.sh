@@ -18,6 +18,18 @@ case "$WHAT" in
 profiles)
   S=gpurun_out/profiles_$TAG
   mkdir -p $S
+  # the vector ALU's throughput per instruction form: the price list of tools/hw.py (tools/valu_peak.hip, built HERE)
+  if [ -x tools/valu_peak ]; then timeout -k 10 200 tools/valu_peak > $S/${TAG}_valu_peak.txt 2>&1 || true; fi
+  # the butterfly statement against occupancy, 1 .. 8 waves per SIMD (tools/stream_occupancy.hip; built right here, stamped with
+  # the hash of the generator + probe it was made from: bench.statement_steady_state quotes it only when that hash is the tree's)
+  if [ ! -x tools/stream_occupancy ]; then
+    { mkdir -p ab && NTT_GEN_W=1 python3 tools/gen_gl_asm.py ab/gl_asm_w.h && hipcc -O3 --offload-arch=gfx950 -I ab tools/stream_occupancy.hip -o tools/stream_occupancy; } > gpurun_out/build_stream_occupancy.log 2>&1 || true
+  fi
+  if [ -x tools/stream_occupancy ]; then
+    { echo "# stream_src_hash $(python3 -c 'import bench; print(bench.stream_source_hash())')"; timeout -k 10 200 tools/stream_occupancy; } > $S/${TAG}_stream_occupancy.txt 2>&1 || true
+  else echo "SKIPPED: stream occupancy table (tools/stream_occupancy failed to build: gpurun_out/build_stream_occupancy.log)"; fi
+  cp $S/${TAG}_valu_peak.txt $S/${TAG}_stream_occupancy.txt profiles/ 2>/dev/null || true  # (on the box: so that the bench line below quotes THIS round's tables)
+  if [ ! -x tools/valu_peak ]; then echo "SKIPPED: valu_peak (tools/valu_peak absent: __graft_entry__.build() makes it)"; fi
   bash tools/collect_profiles.sh $TAG > gpurun_out/collect.log 2>&1 || { tail -40 gpurun_out/collect.log; exit 1; }
   tail -5 gpurun_out/collect.log
   python3 tools/power_probe.py > $S/${TAG}_power_probe.txt 2>&1 || true
@@ -40,17 +52,6 @@ profiles)
     timeout -k 10 300 python3 tools/phase_stamps.py --trace-prefix $S/trace/trace_mi355x_n16 --trace-cycles 150000 > $S/${TAG}_phase_stamps.json 2> gpurun_out/stamps.err || tail -3 gpurun_out/stamps.err
     timeout -k 10 300 python3 tools/phase_stamps.py --logn 12 --p 3221225473 --g 5 --word-bytes 4 --batch 1024 --shape 4,0,8,512 > $S/${TAG}_phase_stamps_cfg2.json 2>> gpurun_out/stamps.err || tail -3 gpurun_out/stamps.err
   fi
-  # the vector ALU's throughput per instruction form: the price list of tools/hw.py (tools/valu_peak.hip, built HERE)
-  if [ -x tools/valu_peak ]; then timeout -k 10 200 tools/valu_peak > $S/${TAG}_valu_peak.txt 2>&1 || true; fi
-  # the butterfly statement against occupancy, 1 .. 8 waves per SIMD (tools/stream_occupancy.hip; built right here, stamped with
-  # the hash of the generator + probe it was made from: bench.statement_steady_state quotes it only when that hash is the tree's)
-  if [ ! -x tools/stream_occupancy ]; then
-    { mkdir -p ab && NTT_GEN_W=1 python3 tools/gen_gl_asm.py ab/gl_asm_w.h && hipcc -O3 --offload-arch=gfx950 -I ab tools/stream_occupancy.hip -o tools/stream_occupancy; } > gpurun_out/build_stream_occupancy.log 2>&1 || true
-  fi
-  if [ -x tools/stream_occupancy ]; then
-    { echo "# stream_src_hash $(python3 -c 'import bench; print(bench.stream_source_hash())')"; timeout -k 10 200 tools/stream_occupancy; } > $S/${TAG}_stream_occupancy.txt 2>&1 || true
-  else echo "SKIPPED: stream occupancy table (tools/stream_occupancy failed to build: gpurun_out/build_stream_occupancy.log)"; fi
-  if [ ! -x tools/valu_peak ]; then echo "SKIPPED: valu_peak (tools/valu_peak absent: __graft_entry__.build() makes it)"; fi
   python3 tools/bench_configs.py > $S/${TAG}_bench_all_configs.jsonl 2> gpurun_out/cfg.err || true
   python3 tools/bench_m64.py > $S/${TAG}_bench_m64.jsonl 2>> gpurun_out/cfg.err || true
   NTT_BENCH_ONE_DEVICE=1 python3 bench.py --gpus 2 --single-process --no-cpu-baseline --no-valu-floor > $S/${TAG}_bench_single_process_rehearsal.json 2>> gpurun_out/cfg.err || true
