@@ -192,7 +192,8 @@ int ntt_polymul_negacyclic(ntt_plan_t plan, void *d_a, void *d_b, void *d_out,
 
 /* Precondition check (blocking, diagnostic): how many of the batch*N words are >= p.  The transforms
  * assume canonical residues, as the reference's vector_modadd / vector_modsub do (src/aie_core.cc:41-62);
- * a non-canonical word gives an unspecified (but memory-safe) result. */
+ * a non-canonical word gives an unspecified (but memory-safe) result: no kernel reads or writes outside the caller's
+ * batch*N words whatever they hold (tests/test_emu_asan.py: the kernels' index rules under AddressSanitizer, exact-size buffers). */
 int ntt_count_noncanonical(ntt_plan_t plan, const void *d_buf, size_t batch, uint64_t *host_count);
 
 /* Reference-style partial network (test_stage hook, src/test.cpp:55-58, 67):

@@ -94,10 +94,12 @@ NTT_HD void stamp(E &ex, int k) {
 }
 constexpr int STAMPS_PER_ITER = 12;    // 2R + 4 <= 12 for R <= 4
 constexpr int STAMP_HEADER = 4;        // 0 s_memrealtime at start, 1 s_memtime at start, 2 HW_ID | XCC_ID << 32, 3 iterations completed
-constexpr int STAMP_RECORD = 128;      // 64-bit slots per wave: header + 8 iterations x 12 stamps, [125] scratch, [126] s_memtime / [127] s_memrealtime at the end
-constexpr int STAMP_ITERS = 8;         // iterations a record has room for; later ones go to STAMP_SCRATCH (GpuExec::stamp)
-constexpr int STAMP_SCRATCH = STAMP_RECORD - 3;
-static_assert(STAMP_HEADER + STAMP_ITERS * STAMPS_PER_ITER <= STAMP_SCRATCH, "stamp record: header + iterations + scratch + two end slots");
+constexpr int STAMP_RECORD = 128;      // 64-bit slots per wave: header + 8 iterations x 12 stamps + one overflow block of 12, [126] s_memtime / [127] s_memrealtime at the end
+constexpr int STAMP_ITERS = 8;         // iterations a record keeps; a wave that streams more (PPW_CAP is 64 for most kernels) stamps all later
+                                       // ones into the overflow block -- it keeps STORING (the LDS-DMA kernels' counted vmcnt includes the stamp
+                                       // stores), but never into a neighbour's record or past the buffer (tools/phase_stamps.py reads 8)
+NTT_HD constexpr int stamp_base(int it) { return (it < STAMP_ITERS ? it : STAMP_ITERS) * STAMPS_PER_ITER; }
+static_assert(STAMP_HEADER + (STAMP_ITERS + 1) * STAMPS_PER_ITER <= STAMP_RECORD - 2, "stamp record: header + iterations + overflow block + two end slots");
 #if defined(NTT_PHASE_STAMPS)
 // every stamp is one more VMEM store of the wave: the LDS-DMA kernels' counted wait (phase_dma_wait) has to know how many of
 // them are younger than the prefetch -- stamps 2 .. 2R+3 of the iteration that issued it and stamp 0 of the next one
@@ -1205,7 +1207,7 @@ NTT_HD void run_pass(Exec &ex, const PassArgs<Cfg> &a) {
         if (!ex.iter_begin(it)) break;  // fused schedule: wait for the producer of this polynomial (uniform)
         ex.each([&](C &c) { phase_begin_iter<Cfg>(c, a, it); });
         typename Cfg::W *const tile = Cfg::DMA ? ex.lds() + (it & 1) * Cfg::TILE_WORDS : ex.lds();
-        const int sb = it * STAMPS_PER_ITER;  // (diagnostic build only: stamp() is nothing elsewhere)
+        const int sb = stamp_base(it);  // (diagnostic build only: stamp() is nothing elsewhere)
         stamp(ex, sb + 0);
         if constexpr (Cfg::DMA) {
             if (it == 0) ex.each([&](C &) { phase_dma_wait<Cfg, true>(); });
