@@ -317,12 +317,6 @@ def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, stream_counts=No
         "frac_of_peak_at_2.4GHz_per_pass": [b / (t * 1e-3) / peak(PEAK_CLOCK_GHZ, c) for b, t, c in zip(bf, per_pass_ms, peak_cyc)],
         "kernels": [e[0] for e in sq_entries],
         "mean_waves_per_simd": waves, "wave_issue_stall_frac": stall,
-        "what": "instr_per_butterfly = SQ_INSTS_VALU of the FORWARD pass kernels / (butterflies / 64); peak cycles per butterfly = its "
-                "VOP3-class instructions x %g cycles + its plain moves / adds x %g (MEASURED steady-state throughput of the forms, %s; "
-                "instructions the counter sees beyond the statement are priced as VOP3-class); peak = %d SIMDs x f / cycles per butterfly x 64 "
-                "lanes; frac_of_peak_at_2.4GHz uses THIS run's pass durations; frac_of_peak_at_held_clock is clock-free: peak cycles x "
-                "wave-butterflies / (SIMDs x GRBM_GUI_ACTIVE/8) of the counter run, held_clock_GHz = GRBM_GUI_ACTIVE / 8 / duration of the "
-                "same profiled launches" % (VALU_PEAK_CYCLES_VOP3, VALU_PEAK_CYCLES_PLAIN, VALU_PEAK_SOURCE, SIMDS),
     }
     if held_note:
         out["held_clock_GHz"], out["held_clock_note"] = held, held_note
@@ -341,15 +335,8 @@ def valu_roofline(sq_entries, passes, per_pass_ms, batch, logn, stream_counts=No
             best = min(v for w, v in st.items() if w >= 4) if any(w >= 4 for w in st) else min(st.values())
             out["statement_alone_steady_state"] = {
                 "cycles_per_butterfly_by_waves_per_simd": st, "cycles_per_butterfly_at_4_or_more_waves": best, "source": statement["source"],
-                "kernel_over_statement": [k / best for k in kcyc],
-                "what": "the forward butterfly statement alone (register-resident radix-8 rounds, many generations of workgroups): what the "
-                        "kernels' rounds could run at if exchanges, loads and stores cost nothing"}
+                "kernel_over_statement": [k / best for k in kcyc]}  # (what the rounds could run at if exchanges, loads and stores cost nothing)
         out["saturated"] = bool(out["frac_of_peak_at_held_clock"] >= SATURATED)
-        wv = "/".join("%.1f" % w for w in waves) if all(w for w in waves) else "~4"
-        out["verdict"] = ("vector ALU at %.0f %% of its measured throughput at the held clock (%s waves per SIMD): %s"
-                          % (100 * out["frac_of_peak_at_held_clock"], wv,
-                             "saturated, an instruction saved returns as time" if out["saturated"] else
-                             "the largest single consumer of the kernels' cycles but not saturated -- LDS exchanges, loads / stores and waits take the rest"))
     return out
 
 
@@ -373,9 +360,10 @@ def sane_clocks(clocks):
 
 
 # ---- the printed line: numbers, not commentary (the reference prints numbers, src/test.cpp:171-174) -------------------------
-# Keys that explain other keys.  `--explain` keeps them (tools/design_table.py and the counter-provenance tests read them); the
-# default line drops them, cuts provenance strings to the file they name and rounds nested floats to 5 significant digits, so
-# that the driver-run line stays below 6 KB.  What every key means: DESIGN.md section 4 ("Reading the line").
+# What every key means is DESIGN.md section 4 ("Reading the line"), not a string in the line.  The few keys that still explain other
+# keys are dropped from the default line, provenance strings are cut to the file they name and nested floats carry 5 significant
+# digits, so that the driver-run line stays below 6 KB; `--explain` prints the full form (provenance in full, full precision:
+# tools/design_table.py and the counter-provenance tests read that).
 PROSE_KEYS = {"what", "definition", "bound_note", "frac_of_practical_hbm_what", "verdict", "data_note"}
 TOP_LEVEL_EXACT = {"value", "ms_per_step", "butterflies_per_s", "ops_per_s_reference_convention"}  # (the last two: 7 digits, below)
 
@@ -762,12 +750,6 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
         # (decide_bound): "hbm" / "valu" only when that unit is at >= 0.95 of what it can do; "power-cap" when neither is and the
         # kernels hold less than 0.9 of the peak clock; "unsaturated" when nothing can be shown.
         "bound": bound, "bound_detail": bound_detail, "roofline_of_fields": "hbm",
-        "bound_note": "achieved/peak/frac are the HBM roofline SURVEY 8(d) prescribes (algorithmic bytes over the spec peak); "
-                      "frac_ceiling is what frac could reach at most with this pass count, frac_of_practical_hbm how close the step is "
-                      "to %d trips at the same-run device-copy rate; roofline.valu is the vector-ALU roofline on the unit's MEASURED "
-                      "throughput (4 cycles per wave64 instruction for the statements' VOP3-class forms, 2 for plain moves: tools/hw.py).  The "
-                      "board power cap (1400 W) sets the clock the kernels hold."
-                      % len(passes),
         "frac_ceiling": 1.0 / len(passes),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
@@ -778,14 +760,7 @@ def rank0_extras(torch, args, plan, table, x, y, stream, passes, out, world):
         "achieved_step": alg_bytes / step_s / 1e9,
         "practical_hbm_floor_ms": practical_ms,
         "frac_of_practical_hbm": practical_ms / (step_s * 1e3),
-        "frac_of_practical_hbm_what": "%d trips x the time a device copy of the same algorithmic bytes takes in this run (%.3f ms each) / "
-                                      "ms_per_step" % (len(passes), copy["ms"]),
         "traffic": traffic, "traffic_source": traffic_src,
-        "definition": "algorithmic bytes of one forward transform (2*N*8 B) x batch / summed duration of its "
-                      "%d pass kernels (hipEvents on the launch stream); frac_step divides by ms_per_step of the timed region instead "
-                      "(kernel gaps included; on a multi-rank job the slowest rank's); a %d-pass transform physically moves %dx its "
-                      "algorithmic bytes, so its ceiling is frac %.2f; traffic = PMC HBM bytes of the same (forward) launches"
-                      % (len(passes), len(passes), len(passes), 1.0 / len(passes)),
         "algorithmic_bytes_per_transform": 2 * n * 8, "algorithmic_bytes_per_launch": alg_bytes,
         "passes": len(passes), "pass_stages": [stages for _, _, stages in passes],
         "pass_ms": [float(v) for v in per_pass], "dominant_pass": dom,
@@ -914,8 +889,8 @@ def config_roofline(cfg_key, c, op_ms, copy_ms, passes, src_hash):
 
     alg = float(algorithmic_bytes(c))
     plain = config_plain_share(c)
-    what = ("VALU wave-instructions per operation at their measured throughput (%g cycles, %.0f %% of them plain moves / adds at %g: %s) / "
-            "(1024 SIMDs x GRBM_GUI_ACTIVE / 8 per operation): clock-free" % (VALU_PEAK_CYCLES_VOP3, 100 * plain, VALU_PEAK_CYCLES_PLAIN, VALU_PEAK_SOURCE))
+    # valu.frac_of_peak_at_held_clock: VALU wave-instructions per operation at their measured throughput (`plain` of them moves / adds) /
+    # (1024 SIMDs x GRBM_GUI_ACTIVE / 8 per operation): clock-free
     achieved = alg / (op_ms * 1e-3) / 1e9
     pmc, pmc_src = tagged_profile("%s_pmc_traffic" % cfg_key, src_hash)
     sq, sq_src = tagged_profile("%s_sq_counters" % cfg_key, src_hash)
@@ -941,8 +916,7 @@ def config_roofline(cfg_key, c, op_ms, copy_ms, passes, src_hash):
                         "frac_of_peak_at_held_clock": valu_frac_of_peak(ins, cyc, plain),
                         "mean_waves_per_simd": [e[1].get("mean_waves_per_simd") for e in ent],
                         "held_clock_GHz": [e[1].get("held_clock_GHz") for e in ent], "kernels": [e[1]["short"] for e in ent],
-                        "kernel_cycles": [e[1].get("kernel_cycles") for e in ent],
-                        "what": what + "; the headline's counters: the same two pass kernels at batch %d (fractions do not depend on the batch)" % hs["batch"]}
+                        "kernel_cycles": [e[1].get("kernel_cycles") for e in ent]}  # (the headline's two kernels: fractions do not depend on the batch)
                 sq_src = hs_src + " -- the headline's launches of the same two kernels"
     if sq and sq["per_op"].get("kernel_cycles"):
         po = sq["per_op"]
@@ -951,8 +925,7 @@ def config_roofline(cfg_key, c, op_ms, copy_ms, passes, src_hash):
                 "mean_waves_per_simd": [k.get("mean_waves_per_simd") for k in sq["kernels"].values()],
                 "held_clock_GHz": [k.get("held_clock_GHz") for k in sq["kernels"].values()],
                 "kernels": [k["short"] for k in sq["kernels"].values()],
-                "kernel_cycles": [k.get("kernel_cycles") for k in sq["kernels"].values()],
-                "what": what}
+                "kernel_cycles": [k.get("kernel_cycles") for k in sq["kernels"].values()]}
     if valu:
         # a clock above the part's peak is not a clock (sane_clocks): null it AND the fraction made of the same cycle count
         valu["held_clock_GHz"], note = sane_clocks(valu["held_clock_GHz"])
@@ -976,9 +949,7 @@ def config_roofline(cfg_key, c, op_ms, copy_ms, passes, src_hash):
             "frac": achieved / HBM_PEAK_GBS, "frac_ceiling": ceiling,
             "traffic": traffic, "traffic_ratio_to_algorithmic": (traffic / alg if traffic else None), "traffic_source": pmc_src,
             "valu": valu, "valu_source": sq_src,
-            "algorithmic_bytes_per_op": alg, "device_copy_same_bytes_GBs": copy_gbs, "frac_of_device_copy": of_copy,
-            "definition": "algorithmic bytes of one operation (SURVEY 8d: 2N words per transform, 9N per product) / hipEvent time per "
-                          "operation (back-to-back operations on the launch stream)"}
+            "algorithmic_bytes_per_op": alg, "device_copy_same_bytes_GBs": copy_gbs, "frac_of_device_copy": of_copy}
 
 
 def run_config(torch, key, stream, src_hash, steps):
