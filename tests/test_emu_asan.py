@@ -50,11 +50,23 @@ def _build_all(tmp):
         return dict(ex.map(one, jobs))
 
 
+def _sanitizers_available(tmp):
+    """g++ with its ASan / UBSan runtimes (this image has them; a toolchain without them skips instead of erroring)"""
+    if shutil.which("g++") is None:
+        return False
+    src = os.path.join(tmp, "probe.cpp")
+    with open(src, "w") as f:
+        f.write("int main() { return 0; }\n")
+    r = subprocess.run(["g++", *SAN, src, "-o", os.path.join(tmp, "probe")], capture_output=True, text=True)
+    return r.returncode == 0 and subprocess.run([os.path.join(tmp, "probe")]).returncode == 0
+
+
 @pytest.fixture(scope="module")
 def sweep_exes(tmp_path_factory):
-    if shutil.which("g++") is None:
-        pytest.skip("no g++")
-    return _build_all(str(tmp_path_factory.mktemp("asan_sweep")))
+    tmp = str(tmp_path_factory.mktemp("asan_sweep"))
+    if not _sanitizers_available(tmp):
+        pytest.skip("no g++ with the ASan / UBSan runtimes")
+    return _build_all(tmp)
 
 
 def _run(exe, fam, *args):
