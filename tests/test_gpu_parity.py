@@ -342,6 +342,19 @@ def test_bench_json_contract():
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
+    # round 6: the line is numbers, not commentary -- a size bound, and no clock above the part's 2.4 GHz anywhere in it
+    assert len(line) < 6144, len(line)
+
+    def leaves(o, path=""):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                yield from leaves(v, path + "/" + k)
+        elif isinstance(o, list):
+            for v in o:
+                yield from leaves(v, path)
+        else:
+            yield path, o
+    assert all(v <= 2.4 * 1.02 for k, v in leaves(d) if "clock" in k and "GHz" in k and isinstance(v, (int, float)))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
               "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
